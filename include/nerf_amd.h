@@ -1,0 +1,140 @@
+/*
+ * nerf_amd.h -- C ABI of the MI355X (gfx950) render hot path of mip-NeRF / SAR-NeRF.
+ *
+ * The upstream project (jsbudge/nerf) is pure Python on top of stock PyTorch ops and has no
+ * FFI of its own, so every entry point below replaces a *sequence of torch ops* in the
+ * reference; the comment on each one cites that sequence as file:line of the reference.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (inputs, outputs, workspaces);
+ *     nothing is allocated, freed or synchronised inside a call;
+ *   - tensors are dense, row-major, fp32 unless a parameter says otherwise;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
+ *     asynchronous with respect to the host;
+ *   - return value: 0 on success, a negative NERF_ERR_* code otherwise (never throws);
+ *   - "rays" are flattened to N rows; per-sample tensors are [N, S, c]; fenceposts [N, S+1].
+ */
+#ifndef NERF_AMD_H
+#define NERF_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_OK 0
+#define NERF_ERR_ARG (-1)      /* null pointer / non-positive size / unsupported option  */
+#define NERF_ERR_LAUNCH (-2)   /* hipLaunchKernel reported an error                       */
+#define NERF_ERR_SIZE (-3)     /* size beyond what the kernel supports                    */
+#define NERF_ERR_RANGE (-4)    /* data-dependent range error (e.g. range bin out of range) */
+
+#define NERF_RAY_CONE 0
+#define NERF_RAY_CYLINDER 1
+
+int nerf_abi_version(void);
+const char* nerf_error_string(int code);
+
+/* ---- (a) sampling, ray casting, positional encodings --------------------------------- */
+
+/* Stratified fenceposts t_vals[N,S+1] between near[N] and far[N] (linear, or linear in
+ * disparity when lindisp != 0).  t_rand[N,S+1] in [0,1) jitters each fencepost inside its
+ * stratum; NULL gives the deterministic spacing.            reference: utils.py:214-228 */
+int nerf_stratified_t(const float* near, const float* far, const float* t_rand, int64_t n_rays,
+                      int num_samples, int lindisp, float* t_vals, void* stream);
+
+/* Conical-frustum (stable form) or cylinder -> diagonal Gaussian per interval:
+ * mean[N,S,3], cov[N,S,3].  radii[N].     reference: utils.py:89-101, 130-137, 162-164, 168-191 */
+int nerf_cast_rays(const float* t_vals, const float* origins, const float* directions,
+                   const float* radii, int64_t n_rays, int num_samples, int ray_shape, float* mean,
+                   float* cov, void* stream);
+
+/* Integrated positional encoding enc[P, 6L], L = max_deg-min_deg, feature k = l*3+c is
+ * exp(-cov_c 4^l / 2) sin(mean_c 2^l), feature 3L+k the same with the angle shifted by
+ * fp32(pi/2).                                          reference: util_modules.py:37-44 */
+int nerf_ipe_encode(const float* mean, const float* cov, int64_t n_points, int min_deg, int max_deg,
+                    float* enc, void* stream);
+
+/* Plain sinusoidal encoding out[P, 6L (+3)]; with append_input != 0 the raw 3-vector is
+ * appended (the view-direction feature row).  reference: util_modules.py:49, model.py:125-126 */
+int nerf_pe_encode(const float* x, int64_t n_points, int min_deg, int max_deg, int append_input,
+                   float* out, void* stream);
+
+/* SAR ray directions ray_d[R,3] and two-way beam power ray_p[R] from azimuth/elevation
+ * offsets (already scaled by the beam sigmas).                reference: model.py:321-325 */
+int nerf_sar_raygen(const float* az, const float* el, int64_t n_rays, float* ray_d, float* ray_p,
+                    void* stream);
+
+/* ---- (c) hierarchical resampling ------------------------------------------------------ */
+
+/* new_t[N,n_out] = inverse-CDF samples of the blurred, padded weights:
+ *   blur (max-pool 2, avg-pool 2) + resample_padding when blur != 0  (utils.py:252-257),
+ *   eps guard, pdf, cdf with exact 0/1 ends                            (utils.py:19-33),
+ *   u = min(2 j/n + u_rand, 1-eps)  or linspace(0, 1-eps, n) if u_rand == NULL (utils.py:36-45),
+ *   interval search (last cdf entry <= u) and lerp                     (utils.py:49-62).
+ * idx_out[N,n_out] (int32, nullable) receives the interval indices, cdf_out[N,S+1]
+ * (nullable) the cdf.  num_samples <= 1023. */
+int nerf_resample(const float* t_vals, const float* weights, const float* u_rand, int64_t n_rays,
+                  int num_samples, int n_out, float resample_padding, int blur, float* new_t,
+                  int32_t* idx_out, float* cdf_out, void* stream);
+
+/* The interval search + lerp stage alone on caller-supplied cdf[N,S+1] and u[N,n_out]
+ * (bit-exact against torch.searchsorted(right=True)-1 + gather).   reference: utils.py:49-62 */
+int nerf_invert_cdf(const float* bins, const float* cdf, const float* u, int64_t n_rays,
+                    int num_fenceposts, int n_out, float* samples, int32_t* idx_out, void* stream);
+
+/* ---- (d) alpha compositing ------------------------------------------------------------- */
+
+/* Activation constants fused in front of the compositing integral (model.py:135-140):
+ * rgb = raw_rgb * (1 + 2 rgb_padding) - rgb_padding, density = softplus(raw_density +
+ * density_bias).  With apply_activation == 0 the inputs are used as they are. */
+typedef struct nerf_activation {
+    int apply_activation;
+    float rgb_padding;
+    float density_bias;
+} nerf_activation;
+
+/* comp_rgb[N,3], distance[N], acc[N], weights[N,S], alpha[N,S] (weights/alpha nullable).
+ * rgb[N,S,3], density[N,S], t_vals[N,S+1], dirs[N,3].        reference: utils.py:299-317 */
+int nerf_composite_fwd(const float* rgb, const float* density, const float* t_vals, const float* dirs,
+                       int64_t n_rays, int num_samples, int white_bkgd, const nerf_activation* act,
+                       float* comp_rgb, float* distance, float* acc, float* weights, float* alpha,
+                       void* stream);
+
+/* Gradient of the above w.r.t. rgb and density inputs (w.r.t. the raw inputs when the
+ * activation is fused).  g_distance / g_acc may be NULL (= zero).  Where the reference's
+ * autograd yields NaN (acc == 0 with a distance gradient) this returns 0. */
+int nerf_composite_bwd(const float* rgb, const float* density, const float* t_vals, const float* dirs,
+                       const float* g_comp_rgb, const float* g_distance, const float* g_acc,
+                       int64_t n_rays, int num_samples, int white_bkgd, const nerf_activation* act,
+                       float* g_rgb, float* g_density, void* stream);
+
+/* ---- (d') SAR scattering + range-bin scatter ------------------------------------------- */
+
+/* One pulse: rgb[R,S,3], angle[R,S,2], density[R,S], power[R], t_vals[R,S+1], dirs[R,3],
+ * pulse_bins[nsam] ascending.  Outputs pulse[nsam,2] (overwritten), distance[R], acc[R],
+ * weights[R,S], alpha[R,S] (nullable), and the per-ray state the backward needs:
+ * ray_ret[R,2], ray_bin[R] (int32), comp[R,5] (composited rgb + angle*3.14).
+ * winner[nsam] (int32) is scratch.  Duplicate bins: the highest ray index wins, as the
+ * reference's non-accumulating `x[idx] += v` does single-threaded.  status[1] (int32,
+ * device) is set to NERF_ERR_RANGE if a distance falls beyond the last bin (the reference
+ * raises IndexError there).                                   reference: utils.py:336-379 */
+int nerf_scatter_fwd(const float* rgb, const float* angle, const float* density, const float* power,
+                     const float* t_vals, const float* dirs, const float* pulse_bins, int64_t n_rays,
+                     int num_samples, int nsam, float wavelength, const nerf_activation* act,
+                     float* pulse, float* distance, float* acc, float* weights, float* alpha,
+                     float* ray_ret, int32_t* ray_bin, float* comp, int32_t* winner, int32_t* status,
+                     void* stream);
+
+/* Gradient of nerf_scatter_fwd w.r.t. rgb, angle, density given g_pulse[nsam,2]; every ray of
+ * a bin receives the bin's gradient (reference autograd behaviour for the indexed +=). */
+int nerf_scatter_bwd(const float* rgb, const float* angle, const float* density, const float* power,
+                     const float* t_vals, const float* dirs, const float* g_pulse,
+                     const int32_t* ray_bin, const float* comp, const float* distance, int64_t n_rays,
+                     int num_samples, int nsam, float wavelength, const nerf_activation* act,
+                     float* g_rgb, float* g_angle, float* g_density, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_AMD_H */
