@@ -134,6 +134,38 @@ int nerf_scatter_bwd(const float* rgb, const float* angle, const float* density,
                      int num_samples, int nsam, float wavelength, const nerf_activation* act,
                      float* g_rgb, float* g_angle, float* g_density, void* stream);
 
+/* ---- (b) MLP, full-precision path ---------------------------------------------------- */
+
+#define NERF_ACT_NONE 0
+#define NERF_ACT_RELU 1
+#define NERF_ACT_SIGMOID 2
+
+/* C[M,N] = act(A[M,K] B[K,N] + bias[N]) on the fp32-input matrix cores (exact fp32 fma chain).
+ * A and B are addressed by (row, col) element strides, so nn.Linear forward (X W^T), its input
+ * gradient (dY W) and its weight gradient (dY^T X) are the same call with different strides.
+ * split_k > 1 splits K over workgroups which add into a caller-zeroed C with fp32 atomics
+ * (bias must be NULL and act NONE then).  reference: every nn.Linear of model.py:54-93, 258-302
+ * (aten::addmm forward, aten::mm x2 backward). */
+int nerf_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs,
+                  const float* bias, float* C, int64_t ldc, int64_t M, int N, int64_t K, int act,
+                  int split_k, void* stream);
+
+/* g[M,N] *= act'(.) evaluated from the activation OUTPUT y (ReLU: y > 0; sigmoid: y (1 - y)).
+ * reference: autograd of nn.ReLU / nn.Sigmoid (model.py:56-72, 92, 297, 301). */
+int nerf_act_bwd_f32(float* g, int64_t ldg, const float* y, int64_t ldy, int64_t M, int N, int act,
+                     void* stream);
+
+/* out[N] += column sums of X[M,N] (bias gradients).  out must be initialised by the caller. */
+int nerf_colsum_f32(const float* X, int64_t ldx, int64_t M, int N, float* out, void* stream);
+
+/* LayerNorm over the last dimension (SAR density head).       reference: model.py:279, 346 */
+int nerf_layernorm_fwd(const float* x, const float* gamma, const float* beta, int64_t M, int H, float eps,
+                       float* y, float* mean, float* rstd, void* stream);
+/* ggamma / gbeta are accumulated with atomics into caller-zeroed buffers. */
+int nerf_layernorm_bwd(const float* x, const float* gamma, const float* gy, const float* mean,
+                       const float* rstd, int64_t M, int H, float* gx, float* ggamma, float* gbeta,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,365 @@
+"""Counterpart of the reference's `model.py`: `MipNeRF` and `SARNeRF` with the same constructor
+(`config`, `return_raw`), the same submodule / `state_dict` key names (so upstream checkpoints
+load and `torch.save(model.state_dict())` is interchangeable) and the same public methods
+(`forward`, `render_image`, `configure_optimizers`, `training_step`, `validation_step`,
+`train_val_get`, `train`, `eval`) -- model.py:26-216, 228-428 -- running on the HIP kernels.
+
+The `nn.Linear` / `nn.LayerNorm` submodules only *hold* the parameters; their `forward` is never
+called.  `config.mlp_precision` selects the MLP path: 'bf16' (fused MFMA chain, default) or
+'fp32' (layer-by-layer fp32 matrix-core GEMMs).  `config.level_samples` (optional list) gives the
+number of intervals per level; upstream uses `config.num_samples` for every level.
+
+The reference subclasses pytorch_lightning.LightningModule; this module only needs `device`,
+`log_dict`, `optimizers`, `lr_schedulers` and `manual_backward` from it, which `_RenderModule`
+provides so the package has no Lightning dependency.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch import optim
+
+from . import mlp, ops
+from .util_modules import MipLRDecay, NeRFLoss, PositionalEncoding, SARNeRFLoss
+from .utils import namedtuple_map
+
+SAR_AZ_SIGMA = 0.039269908169872414     # model.py:319
+SAR_EL_SIGMA = 0.09599310885968812      # model.py:320
+
+
+def to8b(img):
+    return (255 * np.clip(img, 0, 1)).astype(np.uint8)
+
+
+def _xavier_init(model):
+    """Xavier-uniform weights; biases keep nn.Linear's default init (model.py:219-225)."""
+    for module in model.modules():
+        if isinstance(module, nn.Linear):
+            nn.init.xavier_uniform_(module.weight)
+
+
+class _RenderModule(nn.Module):
+    """The slice of the LightningModule interface the render models use."""
+
+    def __init__(self):
+        super().__init__()
+        self.automatic_optimization = False
+        self._optim = None
+        self.logged = {}
+
+    @property
+    def device(self):
+        p = next(self.parameters(), None)
+        return p.device if p is not None else torch.device('cpu')
+
+    def log_dict(self, metrics, **_):
+        self.logged = {k: (float(v) if torch.is_tensor(v) else v) for k, v in metrics.items()}
+
+    def _ensure_optim(self):
+        if self._optim is None:
+            self._optim = self.configure_optimizers()
+        return self._optim
+
+    def optimizers(self):
+        return self._ensure_optim()['optimizer']
+
+    def lr_schedulers(self):
+        return self._ensure_optim()['lr_scheduler']
+
+    def manual_backward(self, loss):
+        loss.backward()
+
+    def configure_optimizers(self):
+        cfg = self.config
+        optimizer = optim.AdamW(self.parameters(), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
+        scheduler = MipLRDecay(optimizer, lr_init=cfg.lr_init, lr_final=cfg.lr_final, max_steps=cfg.max_steps,
+                               lr_delay_steps=cfg.lr_delay_steps, lr_delay_mult=cfg.lr_delay_mult)
+        return {'optimizer': optimizer, 'lr_scheduler': scheduler}
+
+    def training_step(self, batch, batch_idx):
+        opt = self.optimizers()
+        train_loss = self.train_val_get(batch, batch_idx)
+        opt.zero_grad()
+        self.manual_backward(train_loss)
+        opt.step()
+        self.lr_schedulers().step()
+        self._weights_changed()
+        return train_loss
+
+    def validation_step(self, batch, batch_idx):
+        with torch.no_grad():
+            self.train_val_get(batch, batch_idx, 'val')
+
+    def train(self, mode=True):
+        self.randomized = self.init_randomized
+        super().train(mode)
+        return self
+
+    def eval(self):
+        self.randomized = False
+        return super().eval()
+
+    def _weights_changed(self):
+        """Hook: packed bf16 weight copies go stale after an optimizer step."""
+        self._packed = None
+
+    # ---- shared pieces ---------------------------------------------------------------------
+    def _build_trunk(self, config):
+        H, D = config.hidden, self.density_input
+
+        def stack(first_in):
+            return nn.Sequential(nn.Linear(first_in, H), nn.ReLU(True), nn.Linear(H, H), nn.ReLU(True),
+                                 nn.Linear(H, H), nn.ReLU(True), nn.Linear(H, H), nn.ReLU(True))
+        self.density_net0 = stack(D)
+        self.density_net1 = stack(D + H)
+
+    def _param_dict(self):
+        return {k: v for k, v in self.named_parameters() if not k.endswith('scales')}
+
+    def _level_samples(self):
+        ls = getattr(self.config, 'level_samples', None)
+        return list(ls) if ls else [self.num_samples] * self.num_levels
+
+    def _precision(self):
+        return getattr(self.config, 'mlp_precision', 'fp32')
+
+
+class MipNeRF(_RenderModule):
+    def __init__(self, config=None, return_raw=False):
+        super().__init__()
+        self.config = config
+        self.use_viewdirs = config.use_viewdirs
+        self.init_randomized = config.randomized
+        self.randomized = config.randomized
+        self.ray_shape = config.ray_shape
+        self.white_bkgd = config.white_bkgd
+        self.num_levels = config.num_levels
+        self.num_samples = config.num_samples
+        self.density_input = (config.max_deg - config.min_deg) * 3 * 2
+        self.rgb_input = 3 + ((config.viewdirs_max_deg - config.viewdirs_min_deg) * 3 * 2)
+        self.density_noise = config.density_noise
+        self.rgb_padding = config.rgb_padding
+        self.resample_padding = config.resample_padding
+        self.density_bias = config.density_bias
+        self.hidden = config.hidden
+        self.return_raw = return_raw
+        self.density_activation = nn.Softplus()
+        self.loss_function = NeRFLoss(config.coarse_weight_decay)
+        if not self.use_viewdirs:
+            raise NotImplementedError('the render kernels implement the view-dependent colour branch '
+                                      '(use_viewdirs=True), the configuration the reference ships')
+
+        self.positional_encoding = PositionalEncoding(config.min_deg, config.max_deg)
+        self._build_trunk(config)
+        self.final_density = nn.Sequential(nn.Linear(config.hidden, 1))
+        self.rgb_net0 = nn.Sequential(nn.Linear(config.hidden, config.hidden))
+        self.viewdirs_encoding = PositionalEncoding(config.viewdirs_min_deg, config.viewdirs_max_deg)
+        # width of the colour layer is `num_samples`, as upstream (model.py:80,87)
+        self.rgb_net1 = nn.Sequential(nn.Linear(config.hidden + self.rgb_input, config.num_samples), nn.ReLU(True))
+        self.final_rgb = nn.Sequential(nn.Linear(config.num_samples, 3), nn.Sigmoid())
+        _xavier_init(self)
+        self._packed = None
+
+    # -- one level of the MLP on [M, D] encodings ------------------------------------------
+    def _query(self, enc, view_feat, S):
+        if self._precision() == 'bf16':
+            from . import mlp_bf16
+            return mlp_bf16.query_nerf(self, enc, view_feat, S)
+        view_rows = view_feat[:, None, :].expand(-1, S, -1).reshape(-1, view_feat.shape[-1])   # model.py:127-128
+        return mlp.mlp_forward_fp32(self._param_dict(), enc, view_rows, sar=False)
+
+    def forward(self, rays, t_rand=None, u_rand=None, noise=None):
+        """rays: `Rays` of `[N, .]` tensors on the model's device.  Optional pre-drawn random
+        tensors (`t_rand [N,S0+1]`, `u_rand {level: [N,S_l+1]}`, `noise {level: [N,S_l,1]}`) replace
+        the draws the reference makes internally, in the same places (model.py:100-151)."""
+        cfg = self.config
+        levels = self._level_samples()
+        o, d = rays.origins, rays.directions
+        n = o.shape[0]
+        view_feat = ops.pe_encode(rays.viewdirs, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg, append_input=True)
+        comp_rgbs, distances, accs = [], [], []
+        t_vals = weights = rgb = density = None
+        for l, S in enumerate(levels):
+            with torch.no_grad():
+                if l == 0:
+                    tr = None
+                    if self.randomized:
+                        tr = t_rand if t_rand is not None else torch.rand(n, S + 1, device=o.device)
+                    t_vals = ops.stratified_t(rays.near, rays.far, S, tr, False)
+                else:
+                    ur = None
+                    if self.randomized:
+                        ur = (u_rand[l] if u_rand is not None else
+                              torch.empty(n, S + 1, device=o.device).uniform_(0, 1 / (S + 1) - float(torch.finfo(torch.float32).eps)))
+                    t_vals = ops.resample(t_vals, weights, S + 1, self.resample_padding, ur, blur=True)
+                mean, cov = ops.cast_rays(t_vals, o, d, rays.radii, self.ray_shape)
+                enc = ops.ipe_encode(mean, cov, cfg.min_deg, cfg.max_deg).reshape(n * S, -1)
+            raw_density, raw_rgb = self._query(enc, view_feat, S)
+            raw_density = raw_density.reshape(n, S, 1)
+            raw_rgb = raw_rgb.reshape(n, S, 3)
+            if self.randomized and self.density_noise:
+                nz = noise[l] if noise is not None else torch.rand(raw_density.shape, device=o.device)
+                raw_density = raw_density + self.density_noise * nz
+            comp_rgb, distance, acc, weights, alpha = ops.composite(
+                raw_rgb, raw_density, t_vals, d, self.white_bkgd, act=(True, self.rgb_padding, self.density_bias))
+            comp_rgbs.append(comp_rgb)
+            distances.append(distance)
+            accs.append(acc)
+        out = (torch.stack(comp_rgbs), torch.stack(distances), torch.stack(accs))
+        if self.return_raw:
+            with torch.no_grad():
+                rgb = raw_rgb * (1 + 2 * self.rgb_padding) - self.rgb_padding
+                density = torch.nn.functional.softplus(raw_density + self.density_bias)
+                raws = torch.cat((rgb, density), -1).cpu()
+            return out + (raws,)
+        return out
+
+    def render_image(self, rays, height, width, chunks=8192):
+        """Chunked no-grad render of one image's rays; keeps the last level (model.py:153-175)."""
+        length = rays[0].shape[0]
+        rgbs, dists, accs = [], [], []
+        with torch.no_grad():
+            for i in range(0, length, chunks):
+                chunk_rays = namedtuple_map(lambda r: r[i:i + chunks].to(self.device), rays)
+                rgb, distance, acc = self(chunk_rays)[:3]
+                rgbs.append(rgb[-1].cpu())
+                dists.append(distance[-1].cpu())
+                accs.append(acc[-1].cpu())
+        rgbs = to8b(torch.cat(rgbs, dim=0).reshape(height, width, 3).numpy())
+        dists = torch.cat(dists, dim=0).reshape(height, width).numpy()
+        accs = torch.cat(accs, dim=0).reshape(height, width).numpy()
+        return rgbs, dists, accs
+
+    def train_val_get(self, batch, batch_idx, kind='train'):
+        rays, pixels = batch
+        rgb = self.forward(rays)[0]
+        train_loss, psnrs = self.loss_function(rgb, pixels, rays.lossmult.to(self.device))
+        self.log_dict({f'{kind}_loss': train_loss, 'coarse_psnr': torch.mean(psnrs[:-1]), 'fine_psnr': psnrs[-1],
+                       'avg_psnr': torch.mean(psnrs), 'LR': self.lr_schedulers().get_last_lr()[0]}, on_epoch=True,
+                      prog_bar=True, rank_zero_only=True)
+        return train_loss
+
+
+class SARNeRF(_RenderModule):
+    def __init__(self, config=None, return_raw: bool = False, *args, **kwargs):
+        super().__init__()
+        self.config = config
+        self.use_viewdirs = config.use_viewdirs
+        self.init_randomized = config.randomized
+        self.randomized = config.randomized
+        self.ray_shape = config.ray_shape
+        self.num_levels = config.num_levels
+        self.num_samples = config.num_samples
+        self.density_input = (config.max_deg - config.min_deg) * 3 * 2
+        self.rgb_input = 3 + ((config.viewdirs_max_deg - config.viewdirs_min_deg) * 3 * 2)
+        self.density_noise = config.density_noise
+        self.rgb_padding = config.rgb_padding
+        self.resample_padding = config.resample_padding
+        self.density_bias = config.density_bias
+        self.hidden = config.hidden
+        self.wavelength = config.wavelength
+        self.total_num_rays = config.total_num_rays
+        self.rays_per_chunk = config.rays_per_chunk
+        self.return_raw = return_raw
+        self.density_activation = nn.Softplus()
+        self.num_ray_iters = int(self.total_num_rays // self.rays_per_chunk)
+        self.cube_dim = int(np.sqrt(self.rays_per_chunk))
+        self.loss_function = SARNeRFLoss(config.coarse_weight_decay)
+        if not self.use_viewdirs:
+            raise NotImplementedError('the render kernels implement the view-dependent branch (use_viewdirs=True)')
+
+        self.positional_encoding = PositionalEncoding(config.min_deg, config.max_deg)
+        self._build_trunk(config)
+        self.final_density = nn.Sequential(nn.LayerNorm(config.hidden), nn.Linear(config.hidden, 1))
+        self.rgb_net0 = nn.Sequential(nn.Linear(config.hidden, config.hidden))
+        self.viewdirs_encoding = PositionalEncoding(config.viewdirs_min_deg, config.viewdirs_max_deg)
+        self.rgb_net1 = nn.Sequential(nn.Linear(config.hidden + self.rgb_input, config.num_samples), nn.ReLU(True))
+        self.final_rgb = nn.Sequential(nn.Linear(config.num_samples, 3), nn.Sigmoid())
+        self.final_angle = nn.Sequential(nn.Linear(config.num_samples, 2), nn.Sigmoid())
+        _xavier_init(self)
+        self._packed = None
+
+    def _query(self, enc, view_feat, R, S):
+        # Row i of the MLP input belongs to ray i // S, but upstream tiles the [1,R,V] view features
+        # along the *sample* axis (model.py:351-354), so row i receives the features of ray i mod R.
+        idx = torch.arange(R * S, device=enc.device) % R
+        return mlp.mlp_forward_fp32(self._param_dict(), enc, view_feat[idx], sar=True)
+
+    def forward(self, ray_o, pan, tilt, mfilt, _radii, _near, _far, nsam, mpp, az_el=None, t_rand=None,
+                u_rand=None):
+        """One pulse (B = 1), as the reference supports (model.py:305-387).  `pan`/`tilt` are unused
+        upstream too.  `az_el[c] = (az, el)` optionally supplies chunk c's beam offsets (already scaled
+        by the beam sigmas); otherwise they are drawn on the CPU generator like upstream.  `t_rand[c]`
+        and `u_rand[c]` optionally supply the sampling draws of chunk c.
+        -> pulses [L,1,nsam,2], distance [L,1,R], acc [L,1,R]"""
+        cfg = self.config
+        dev = self.device
+        if ray_o.shape[0] != 1:
+            raise ValueError('SARNeRF.forward handles one pulse per call (B = 1), like the reference')
+        L, S, R = self.num_levels, self.num_samples, self.rays_per_chunk
+        f32 = lambda x: torch.as_tensor(x, dtype=torch.float32, device=dev).reshape(-1)
+        near_s, far_s, rad_s, mpp_s = f32(_near)[0], f32(_far)[0], f32(_radii)[0], f32(mpp)[0]
+        near = near_s.expand(R).contiguous()
+        far = far_s.expand(R).contiguous()
+        radii = rad_s.expand(R).contiguous()
+        pulse_bins = torch.arange(nsam, device=dev) * mpp_s + near_s                           # model.py:316
+        origins = ray_o.to(dev, torch.float32).reshape(1, 3).expand(R, 3).contiguous()
+        comp = [torch.zeros(nsam, 2, device=dev) for _ in range(L)]
+        distances, accs = [None] * L, [None] * L
+        raw_rgb = raw_density = None
+        for c in range(self.num_ray_iters):
+            if az_el is not None:
+                az, el = az_el[c]
+            else:                                                                              # model.py:319-320
+                az = torch.randn(R) * SAR_AZ_SIGMA
+                el = torch.randn(R) * SAR_EL_SIGMA
+            ray_d, ray_p = ops.sar_raygen(az.to(dev), el.to(dev))
+            view_feat = ops.pe_encode(ray_d, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg, append_input=True)
+            t_vals = weights = None
+            for l in range(L):
+                with torch.no_grad():
+                    if l == 0:
+                        tr = None
+                        if self.randomized:
+                            tr = t_rand[c] if t_rand is not None else torch.rand(R, S + 1, device=dev)
+                        t_vals = ops.stratified_t(near, far, S, tr, False)
+                    else:
+                        ur = None
+                        if self.randomized:
+                            ur = (u_rand[c] if u_rand is not None else
+                                  torch.empty(R, S + 1, device=dev).uniform_(0, 1 / (S + 1) - float(torch.finfo(torch.float32).eps)))
+                        t_vals = ops.resample(t_vals, weights, S + 1, self.resample_padding, ur, blur=True)
+                    mean, cov = ops.cast_rays(t_vals, origins, ray_d, radii, self.ray_shape)
+                    enc = ops.ipe_encode(mean, cov, cfg.min_deg, cfg.max_deg).reshape(R * S, -1)
+                raw_density, raw_rgb, angle = self._query(enc, view_feat, R, S)
+                if self.randomized and self.density_noise:
+                    raw_density = raw_density + self.density_noise * torch.rand(raw_density.shape, device=dev)
+                pulse, distance, acc, weights, alpha, _, status = ops.scatter(
+                    raw_rgb.reshape(R, S, 3), angle.reshape(R, S, 2), raw_density.reshape(R, S), ray_p, t_vals, ray_d,
+                    pulse_bins, self.wavelength, act=(True, self.rgb_padding, self.density_bias))
+                comp[l] = comp[l] + pulse
+                distances[l] = distance
+                accs[l] = acc
+        mf = mfilt.to(dev)
+        outs = []
+        for l in range(L):                                                                     # model.py:377-380
+            z = torch.view_as_complex(comp[l][None].contiguous())
+            z = torch.fft.ifft(mf * torch.fft.fft(z, mf.shape[-1], dim=-1), dim=-1)[..., :nsam]
+            z = z / torch.std(z, dim=-1)[..., None]
+            outs.append(torch.view_as_real(z))
+        out = (torch.stack(outs), torch.stack(distances)[:, None], torch.stack(accs)[:, None])
+        if self.return_raw:
+            with torch.no_grad():
+                rgb = raw_rgb.reshape(1, R, S, 3) * (1 + 2 * self.rgb_padding) - self.rgb_padding
+                density = torch.nn.functional.softplus(raw_density.reshape(1, R, S, 1) + self.density_bias)
+                raws = torch.cat((rgb, density), -1).cpu()
+            return out + (raws,)
+        return out
+
+    def train_val_get(self, batch, batch_idx, kind='train'):
+        ray_o, pan, tilt, mfilt, radii, near, far, mpp, pulse_data = batch
+        rgb = self.forward(ray_o, pan, tilt, mfilt, radii, near, far, pulse_data.shape[1], mpp)[0]
+        train_loss, psnrs = self.loss_function(rgb, pulse_data)
+        self.log_dict({f'{kind}_loss': train_loss, 'coarse_psnr': torch.mean(psnrs[:-1]), 'fine_psnr': psnrs[-1],
+                       'avg_psnr': torch.mean(psnrs), 'LR': self.lr_schedulers().get_last_lr()[0]}, on_epoch=True,
+                      prog_bar=True, rank_zero_only=True)
+        return train_loss

@@ -1,0 +1,176 @@
+"""End-to-end render (sample -> encode -> MLP -> composite, two levels, loss, gradients) on the
+HIP kernels with the fp32 MLP path, against the fixtures captured from the reference and against
+the CPU oracle.  Tolerance: 1e-4 relative (fp32), as the parity gate states; gradients 1e-3 of the
+tensor's max (split-K fp32 atomics reorder the sums)."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from tests.conftest import T, cfg_from, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def G(a):
+    return T(a).cuda()
+
+
+def test_gemm_f32_shapes():
+    from nerf_amd import mlp
+    g = torch.Generator().manual_seed(0)
+    for m, n, k in ((300, 256, 60), (1000, 1, 256), (513, 3, 128), (129, 156, 183), (64, 256, 316)):
+        x = torch.randn(m, k, generator=g)
+        w = torch.randn(n, k, generator=g) / k ** 0.5
+        b = torch.randn(n, generator=g)
+        for act, f in (('relu', torch.relu), (None, lambda v: v), ('sigmoid', torch.sigmoid)):
+            xr = x.clone().requires_grad_(True)
+            wr = w.clone().requires_grad_(True)
+            br = b.clone().requires_grad_(True)
+            ref = f(torch.nn.functional.linear(xr.double(), wr.double(), br.double()))
+            gy = torch.randn(m, n, generator=g)
+            ref.backward(gy.double())
+            xg, wg, bg = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+            got = mlp.linear(xg, wg, bg, act)
+            got.backward(gy.cuda())
+            assert relerr(got.cpu(), ref) < 2e-6
+            assert relerr(xg.grad.cpu(), xr.grad) < 2e-6
+            assert relerr(wg.grad.cpu(), wr.grad) < 1e-5
+            assert relerr(bg.grad.cpu(), br.grad) < 1e-5
+
+
+def test_layernorm():
+    from nerf_amd import mlp
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(77, 156, generator=g)
+    ga, be = torch.rand(156, generator=g) + 0.5, torch.randn(156, generator=g)
+    gy = torch.randn(77, 156, generator=g)
+    xr, gr, br = (t.clone().double().requires_grad_(True) for t in (x, ga, be))
+    torch.nn.functional.layer_norm(xr, (156,), gr, br, 1e-5).backward(gy.double())
+    xg, gg, bg = (t.clone().cuda().requires_grad_(True) for t in (x, ga, be))
+    y = mlp.layer_norm(xg, gg, bg)
+    y.backward(gy.cuda())
+    assert relerr(y.detach().cpu(), torch.nn.functional.layer_norm(x, (156,), ga, be, 1e-5)) < 1e-5
+    assert relerr(xg.grad.cpu(), xr.grad) < 1e-4
+    assert relerr(gg.grad.cpu(), gr.grad) < 1e-5 and relerr(bg.grad.cpu(), br.grad) < 1e-5
+
+
+def _model(cfg, levels, wseed, sar=False):
+    from nerf_amd.model import MipNeRF, SARNeRF
+    cfg.mlp_precision = 'fp32'
+    cfg.level_samples = levels
+    m = (SARNeRF if sar else MipNeRF)(cfg).cuda()
+    p = O.init_params(cfg, sar=sar, seed=wseed)
+    missing = m.load_state_dict(p, strict=False)
+    assert all(k.endswith('scales') for k in missing.missing_keys) and not missing.unexpected_keys
+    return m.train()
+
+
+def _rays(fx):
+    from nerf_amd.utils import Rays
+    return Rays(*(G(fx['ray_' + k]) for k in ('origins', 'directions', 'viewdirs', 'radii', 'lossmult', 'near', 'far')))
+
+
+@pytest.mark.parametrize('tag', ['small', 'small_det', 'c1', 'c3'])
+def test_nerf_end_to_end_golden(golden, tag):
+    fx = golden('nerf_e2e_' + tag)
+    cfg = cfg_from(fx)
+    levels = [int(x) for x in fx['levels']]
+    m = _model(cfg, levels, int(fx['wseed']))
+    rays = _rays(fx)
+    t_rand = G(fx['t_rand']) if 't_rand' in fx else None
+    u_rand = {l: G(fx[f'u_rand_{l}']) for l in range(1, len(levels))} if 't_rand' in fx else None
+    rgb, dist, acc = m(rays, t_rand=t_rand, u_rand=u_rand)
+    assert relerr(rgb.cpu(), T(fx['rgb'])) < 1e-4
+    assert relerr(dist.cpu(), T(fx['dist'])) < 1e-4
+    assert relerr(acc.cpu(), T(fx['acc'])) < 1e-4
+    loss, psnr = m.loss_function(rgb, G(fx['target']), rays.lossmult)
+    assert abs(float(loss) - float(fx['loss'])) < 1e-4 * abs(float(fx['loss']))
+    loss.backward()
+    for k, v in m.named_parameters():
+        if k.endswith('scales'):
+            continue
+        if 'grad_' + k in fx:
+            assert relerr(v.grad.cpu(), T(fx['grad_' + k])) < 1e-3, k
+        else:
+            assert abs(float(v.grad.norm()) - float(fx['gnorm_' + k])) < 1e-3 * float(fx['gnorm_' + k]) + 1e-9, k
+            assert relerr(v.grad.cpu().reshape(-1)[::97][:256], T(fx['gslice_' + k])) < 5e-3, k
+
+
+def test_state_dict_keys_match_reference_layout():
+    from nerf_amd.model import MipNeRF, SARNeRF
+    cfg = SimpleNamespace(use_viewdirs=True, randomized=True, ray_shape='cone', white_bkgd=False, num_levels=2,
+                          num_samples=32, min_deg=0, max_deg=4, viewdirs_min_deg=0, viewdirs_max_deg=4,
+                          density_noise=0., rgb_padding=0.001, resample_padding=0.01, density_bias=-1., hidden=64,
+                          coarse_weight_decay=0.1, lr_init=1e-3, lr_final=5e-5, max_steps=10, lr_delay_steps=0,
+                          lr_delay_mult=1, weight_decay=1e-5, wavelength=0.03, total_num_rays=64, rays_per_chunk=64)
+    nerf_keys = set(MipNeRF(cfg).state_dict())
+    assert nerf_keys == set(O.init_params(cfg)) | {'positional_encoding.scales', 'viewdirs_encoding.scales'}
+    sar_keys = set(SARNeRF(cfg).state_dict())
+    assert sar_keys == set(O.init_params(cfg, sar=True)) | {'positional_encoding.scales', 'viewdirs_encoding.scales'}
+
+
+@pytest.mark.parametrize('tag', ['rand', 'det'])
+def test_sar_end_to_end(golden, tag):
+    """SARNeRF.forward against (a) the reference fixture and (b) the oracle at a long wavelength where the
+    fp32 phase is well conditioned, so pulses and all 28 parameter gradients compare elementwise."""
+    fx = golden('sar_e2e_' + tag)
+    cfg = cfg_from(fx)
+    chunks = cfg.total_num_rays // cfg.rays_per_chunk
+    az_el = [(T(fx[f'az_{c}']), T(fx[f'el_{c}'])) for c in range(chunks)]
+    t_rand = [T(fx[f't_rand_{c}']) for c in range(chunks)] if cfg.randomized else None
+    u_rand = [T(fx[f'u_rand_{c}']) for c in range(chunks)] if cfg.randomized else None
+    mfilt = torch.complex(T(fx['mfilt_re']), T(fx['mfilt_im']))
+    nsam = int(fx['nsam'])
+    args = (T(fx['ray_o']), None, None, mfilt, T(fx['radii']), T(fx['near']), T(fx['far']), nsam, T(fx['mpp']))
+
+    m = _model(cfg, None, int(fx['wseed']), sar=True)
+    cu = lambda xs: None if xs is None else [x.cuda() for x in xs]
+    pulses, dist, acc = m(*args, az_el=az_el, t_rand=cu(t_rand), u_rand=cu(u_rand))
+    assert relerr(acc.cpu(), T(fx['acc'])) < 1e-4
+    assert relerr(dist.cpu(), T(fx['dist'])) < 1e-5
+    ref = T(fx['pulses'])
+    frac_bad = float(((pulses.cpu() - ref).abs() > 2e-2 * ref.abs().max()).float().mean())
+    assert frac_bad < 0.15, frac_bad           # 3 cm wavelength: fp32 phase noise, see test_scatter_golden
+
+    # (b) long wavelength, elementwise
+    cfg2 = cfg_from(fx)
+    cfg2.wavelength = 40.0
+    m2 = _model(cfg2, None, int(fx['wseed']), sar=True)
+    p = {k: v.requires_grad_(True) for k, v in O.init_params(cfg2, sar=True, seed=int(fx['wseed'])).items()}
+    ur = [{1: u} for u in u_rand] if u_rand is not None else None
+    ref_p, ref_d, ref_a, _ = O.sar_render(p, T(fx['ray_o']), az_el, mfilt, float(fx['radii'][0]), float(fx['near'][0]),
+                                          float(fx['far'][0]), nsam, float(fx['mpp'][0]), cfg2, t_rand, ur)
+    got_p, got_d, got_a = m2(*args, az_el=az_el, t_rand=cu(t_rand), u_rand=cu(u_rand))
+    assert relerr(got_d.cpu(), ref_d) < 1e-5 and relerr(got_a.cpu(), ref_a) < 1e-4
+    assert relerr(got_p.cpu(), ref_p) < 2e-3
+    tgt = T(fx['target'])
+    O.sar_loss(ref_p, tgt, cfg2.coarse_weight_decay)[0].backward()
+    m2.loss_function(got_p, tgt.cuda())[0].backward()
+    # In the deterministic fixture every ray lands in one range bin; the normalised pulse is then invariant
+    # to the return's amplitude and the colour-branch gradients are analytically ~0 (rounding noise only), so
+    # errors are measured against the largest gradient of the whole model as well as the tensor's own.
+    scale = max(float(p[k].grad.abs().max()) for k in p)
+    for k, v in m2.named_parameters():
+        if k.endswith('scales'):
+            continue
+        err = float((v.grad.cpu() - p[k].grad).abs().max())
+        assert err < 2e-2 * float(p[k].grad.abs().max()) + 1e-4 * scale, k
+
+
+def test_training_step_runs_and_descends(golden):
+    fx = golden('nerf_e2e_small')
+    cfg = cfg_from(fx)
+    m = _model(cfg, [16, 16], int(fx['wseed']))
+    rays, tgt = _rays(fx), G(fx['target'])
+    losses = [float(m.training_step((rays, tgt), i)) for i in range(30)]
+    assert losses[-1] < losses[0]
+    # Upstream, eval() sets randomized=False and then nn.Module.eval() calls the overridden train(False),
+    # which restores randomized=init_randomized -- the jitter stays on.  Reproduced; switch it off by hand.
+    m.eval()
+    assert m.randomized == cfg.randomized and not m.training
+    m.randomized = False
+    a = m(rays)[0]
+    b = m(rays)[0]
+    assert torch.equal(a, b)
