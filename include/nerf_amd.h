@@ -166,6 +166,48 @@ int nerf_layernorm_bwd(const float* x, const float* gamma, const float* gy, cons
                        const float* rstd, int64_t M, int H, float* gx, float* ggamma, float* gbeta,
                        void* stream);
 
+/* ---- (b) MLP, fused bf16 MFMA path --------------------------------------------------- */
+
+/* Logical layer sizes: enc_dim = 6 (max_deg - min_deg), view_dim = 3 + 6 (viewdirs degrees),
+ * hidden = config.hidden, width = config.num_samples (the colour layer's width upstream),
+ * sar != 0 selects the SAR heads (LayerNorm before the density head, extra angle head). */
+typedef struct nerf_mlp_dims {
+    int enc_dim, view_dim, hidden, width, sar;
+} nerf_mlp_dims;
+
+/* Byte sizes of the packed bf16 weight streams and length of the fp32 constants block for a
+ * geometry; NERF_ERR_SIZE when no kernel is instantiated for it. */
+int nerf_mlp_sizes(const nerf_mlp_dims* dims, int64_t* wfwd_bytes, int64_t* wbwd_bytes,
+                   int64_t* consts_floats);
+
+/* Repack the fp32 [out,in] weights of the 10 streamed layers (density_net0.{0,2,4,6},
+ * density_net1.{0,2,4,6}, rgb_net0.0, rgb_net1.0, in that order) into MFMA A-operand fragment
+ * order: wfwd for the forward chain, wbwd (nullable) transposed for the backward chain.  Call
+ * after every optimizer step.                     reference: the nn.Linear weights of model.py:54-93 */
+int nerf_mlp_pack(const nerf_mlp_dims* dims, const float* const* weights, void* wfwd, void* wbwd,
+                  void* stream);
+
+/* (a2)+(a3) fused for the bf16 path: fenceposts -> Gaussians -> integrated positional encoding,
+ * emitted as bf16 B-operand fragments [nblk][ceil(6L/16)][2][64][8], nblk = ceil(N*S/256)*4 blocks
+ * of 64 samples (padding samples are zero).  reference: utils.py:168-191 + util_modules.py:37-44 */
+int nerf_encode_frag(const float* t_vals, const float* origins, const float* directions,
+                     const float* radii, int64_t n_rays, int num_samples, int ray_shape, int min_deg,
+                     int max_deg, void* enc_frag, void* stream);
+
+/* View-direction features [PE(d) | d] per ray as bf16 fragments [n_rays][ceil((6Lv+3)/16)][2][8].
+ *                                              reference: util_modules.py:49, model.py:125-126 */
+int nerf_view_frag(const float* dirs, int64_t n_rays, int min_deg, int max_deg, void* out, void* stream);
+
+/* Forward chain for n_samples rows: raw_density[M], raw_rgb[M,3] (after the sigmoid),
+ * raw_angle[M,2] (SAR).  Row m takes the view features of ray m / ray_div (NeRF, ray_div = samples
+ * per ray) or m % ray_div (SAR, ray_div = rays per chunk -- the row order upstream produces,
+ * model.py:351-354).  acts: NULL for inference, else 11 device pointers (X0..X9 activations and
+ * the view operand) that receive the bf16 fragments the backward pass reads; each sized
+ * nblk * features * 128 bytes.                        reference: model.py:117-132, 343-359 */
+int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* consts, const void* enc_frag,
+                 const void* view_frag, int64_t n_samples, int ray_div, int64_t n_rays, void* const* acts,
+                 float* raw_density, float* raw_rgb, float* raw_angle, float* ln_stats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,7 @@ UNITS = {
     'sampling.hip': ['-ffp-contract=off'],
     'composite.hip': ['-ffp-contract=off'],
     'gemm_f32.hip': [],
-    'mlp_bf16.hip': [],
+    'mlp_bf16.hip': [],      # default contraction: MFMA chain, fp32 epilogues
 }
 
 

@@ -1,0 +1,630 @@
+// The density/colour MLP (and the SAR head variant) as fused bf16 MFMA kernels for gfx950.
+//
+// Formulation.  Every layer is computed transposed, Y^T[features x samples] = W * X^T, with
+// v_mfma_f32_32x32x16_bf16: the weight tile is the A operand, the activations are the B operand.
+// A 32x32 fp32 accumulator tile has its sample column on the lane and its 16 feature rows in
+// registers, which is exactly the B-operand register image of the NEXT layer (whose reduction runs
+// over this layer's features).  Activations therefore never leave registers between layers: a wave
+// owns 64 samples (two 32-wide column tiles) and carries all 256 features of them as 128 VGPRs of
+// packed bf16.  Only weights move: they are packed once per optimizer step into the exact A-operand
+// fragment order and streamed L2 -> LDS with global_load_lds (one 1 KiB piece per wave instruction),
+// double buffered per output tile ("stage"), shared by the 4 waves of a workgroup.
+//
+// Fragment order ("frag").  A k-step covers 16 features; lane l = 32*h + c (c = sample column,
+// h = lane half) holds 8 bf16, element j being feature 16*s + 8*(j>>2) + 4*h + (j&3) of k-step s.
+// This is the order in which the accumulator rows of a finished tile fall into B operands, so the
+// same permutation is baked into the packed weights and into every activation / gradient buffer:
+//   frag buffer of F features:  [block of 64 samples][F/16 k-steps][2 column tiles][64 lanes][8] bf16.
+//
+// Kernels: weight packing (forward and transposed streams), fused cast+IPE encoder and view-feature
+// encoder emitting frags, the forward chain, the backward chain (dX through all layers, emitting dY
+// frags), and the weight-gradient GEMM dW = dY^T X that transposes frags through LDS with
+// ds_read_b64_tr_b16.  bf16 inputs, fp32 accumulation; biases, heads and all epilogue math in fp32.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+// feature index inside a 32-row tile of accumulator register r for lane half h
+__device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// feature index inside a 16-feature k-step of fragment element j for lane half h
+__device__ __host__ __forceinline__ constexpr int frag_feat(int j, int h) { return 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// max(x, 0) as one v_med3_f32 (no NaN canonicalisation pass in front of it)
+__device__ __forceinline__ float relu_f(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+// ReLU on packed bf16: a negative bf16 is a negative int16, so a packed signed max with 0 clears it
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 relu_bf16(bf16x8 x) {
+    s16x8 v = __builtin_bit_cast(s16x8, x);
+    v = __builtin_elementwise_max(v, (s16x8)(0));
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Network geometry (compile time).  HT/WT: 32-row tiles of the hidden width / colour-layer width;
+// DKS/VKS: 16-feature k-steps of the (padded) position / view encodings.
+template <int HT_, int WT_, int DKS_, int VKS_, bool SAR_>
+struct Net {
+    static constexpr int HT = HT_, WT = WT_, DKS = DKS_, VKS = VKS_;
+    static constexpr bool SAR = SAR_;
+    static constexpr int HKS = 2 * HT, WKS = 2 * WT, HP = 32 * HT, WP = 32 * WT;
+    static constexpr int NHEAD = SAR ? 5 : 3;            // rgb (3) [+ angle (2)]
+    // fp32 constants block (floats): biases, laid out per 32-row tile like the accumulators read them
+    static constexpr int C_BIAS = 0;                     // layers 0..8: 9 x HP
+    static constexpr int C_BIAS9 = 9 * HP;               // colour layer: WP
+    static constexpr int C_BIASD = C_BIAS9 + WP;         // density head tile: 32 (row 0 = bias)
+    static constexpr int C_BIASH = C_BIASD + 32;         // rgb/angle head tile: 32 (rows 0..4 = biases)
+    static constexpr int C_SC = C_BIASH + 32;            // scalars: [6] sum(w*gamma) [7] sum(w*beta) [8] 1/H [9] eps
+    static constexpr int C_TOTAL = C_SC + 16;
+    static constexpr int SLOT_KS = HKS + (DKS > VKS ? DKS : VKS);
+    static constexpr int FWD_LDS = C_TOTAL * 4 + 2 * SLOT_KS * 1024;
+    static constexpr int BWD_SLOT_KS = HKS > WKS ? HKS : WKS;
+    static constexpr int BWD_LDS = C_TOTAL * 4 + 2 * BWD_SLOT_KS * 1024;
+    // pieces (1 KiB) in the packed streams
+    // forward: L0, L1-3, L4, L5-7, density head tile, L8, L9, rgb/angle head tile
+    static constexpr int FWD_PIECES = HT * DKS + 3 * HT * HKS + HT * (HKS + DKS) + 3 * HT * HKS + HKS + HT * HKS +
+                                      WT * (HKS + VKS) + WKS;
+    // backward: heads^T (1 k-step), L9^T, L8^T (+1 k-step: density head row), L7..L5^T, L4^T, L3..L1^T
+    static constexpr int BWD_PIECES = WT * 1 + HT * WKS + HT * (HKS + 1) + 7 * HT * HKS;
+};
+
+struct MlpFwdArgs {
+    const bf16x8* wfwd;        // packed forward weight stream
+    const float* consts;       // Net::C_TOTAL floats
+    const bf16x8* enc;         // [nblk][DKS][2][64]
+    const bf16x8* view;        // [n_rays][VKS][2]   (k-step, lane half)
+    int64_t M;                 // real samples
+    int64_t nblk;              // blocks of 64 samples
+    int ray_div;               // NeRF: samples per ray S (ray = m / S);  SAR: rays per chunk R (ray = m % R)
+    int n_rays;
+    bf16x8* act[10];           // saved activations X0..X9 (NULL pointers: inference, nothing saved)
+    bf16x8* act_view;          // saved view operand [nblk][VKS][2][64]
+    float* raw_density;        // [M]
+    float* raw_rgb;            // [M,3]  (post sigmoid)
+    float* raw_angle;          // [M,2]  (SAR, post sigmoid)
+    float* ln_stats;           // [M,2]  (SAR: mean, rstd of the trunk output) nullable
+};
+
+// ------------------------------------------------------------------------------------------------
+// Weight stream: 1 KiB pieces consumed strictly in order.  Stage = the pieces of one output tile.
+// A workgroup is 8 waves (two per SIMD); wave w owns the 32-sample column tile (w & 1) of block
+// 4*blockIdx + (w >> 1) and loads pieces w, w+8, ... of every stage.
+constexpr int kWaves = 8;
+
+struct WeightPipe {
+    const char* src;           // next piece to prefetch (wave-uniform)
+    unsigned slot_bytes;
+    LDS_AS char* ring;         // two slots
+    int cur;                   // slot holding the stage being consumed
+    int wave, lane;
+
+    template <int KS>
+    __device__ __forceinline__ void prefetch(int slot) {
+        if (KS == 0) return;
+        LDS_AS char* dst = ring + slot * slot_bytes;
+#pragma unroll
+        for (int p = 0; p < (KS + kWaves - 1) / kWaves; ++p) {
+            const int piece = p * kWaves + wave;
+            if ((p + 1) * kWaves <= KS || piece < KS)
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + piece * 1024 + lane * 16),
+                                                 (LDS_AS void*)(dst + piece * 1024), 16, 0, 0);
+        }
+        src += KS * 1024;
+    }
+    // Every piece this wave prefetched has landed, except that the YOUNGER most recent vector-memory
+    // operations (activation stores issued after the prefetch) may stay in flight; then the workgroup
+    // barrier makes all waves' pieces visible.
+    template <int YOUNGER>
+    __device__ __forceinline__ void arrive() {
+        // Pin the instruction schedule at the stage boundary: without it the scheduler drifts one stage's
+        // register-only epilogue across several later stages and keeps all their accumulators alive.
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        cur ^= 1;
+    }
+    __device__ __forceinline__ bf16x8 piece(int ks) const {
+        return *(const LDS_AS bf16x8*)(ring + cur * slot_bytes + ks * 1024 + lane * 16);
+    }
+};
+
+enum { EPI_PLAIN = 0, EPI_TRUNK = 1, EPI_HEAD = 2 };
+
+// One layer: NT output tiles; inputs = KS_M k-steps from `xm` then KS_E k-steps from `xe`.
+// On entry the current pipe slot holds the layer's first stage.  NEXT_KS = piece count of the stage
+// that follows this layer's last one (0 at the end of the network).
+//   EPI_PLAIN: activation -> bf16 B operand of the next layer (and saved for the backward pass);
+//   EPI_TRUNK: as PLAIN, plus (SAR) running sum / sum of squares of the fp32 outputs for the LayerNorm;
+//   EPI_HEAD : a single 32-row tile whose first rows are network outputs; returned in `head` as fp32.
+template <class N, bool SAVE, int NT, int KS_M, int KS_E, int NEXT_KS, bool RELU, int EPI, int KM, int KE, int KO>
+__device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[KM], const bf16x8 (&xe)[KE],
+                                          bf16x8 (&out)[KO], const float* bias, int h, bf16x8* save, int64_t blk,
+                                          int ct, float (&head)[4], float (&ln)[2]) {
+    constexpr int KS = KS_M + KS_E;
+    const int lane = pipe.lane;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (nt + 1 < NT) pipe.template prefetch<KS>(pipe.cur ^ 1);
+        else pipe.template prefetch<NEXT_KS>(pipe.cur ^ 1);
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = *(const f32x4*)(bias + nt * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[4 * g + q] = b[q];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 a = pipe.piece(ks);
+            const bf16x8 b = ks < KS_M ? xm[ks < KS_M ? ks : 0] : xe[ks >= KS_M ? ks - KS_M : 0];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+        if (EPI == EPI_HEAD) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) head[q] = acc[q];          // rows 4h .. 4h+3 of the tile
+        } else {
+            if (EPI == EPI_TRUNK && N::SAR) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float x = relu_f(acc[r]);
+                    ln[0] += x;
+                    ln[1] += x * x;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (__bf16)acc[8 * s + j];
+                if (RELU) o = relu_bf16(o);
+                out[2 * nt + s] = o;
+                if (SAVE) save[((blk * (2 * NT) + 2 * nt + s) * 2 + ct) * 64 + lane] = o;
+            }
+        }
+        // next stage must have landed; the 2 activation stores just issued (the youngest vector-memory
+        // operations of this wave) may stay in flight
+        pipe.template arrive<(SAVE && EPI != EPI_HEAD) ? 2 : 0>();
+    }
+}
+
+// grid = nblk / 4 workgroups of 512 threads; every buffer indexed by block is allocated for nblk (a
+// multiple of 4) blocks of 64 samples; samples >= M are padding (zero encodings in, nothing written
+// to the per-sample outputs).
+template <class N, bool SAVE>
+__global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cst = (float*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int ct = wave & 1;
+    const int64_t blk = (int64_t)blockIdx.x * 4 + (wave >> 1);
+
+    for (int i = tid; i < N::C_TOTAL; i += 512) cst[i] = a.consts[i];
+
+    bf16x8 enc[N::DKS], view[N::VKS];
+#pragma unroll
+    for (int ks = 0; ks < N::DKS; ++ks) enc[ks] = a.enc[((blk * N::DKS + ks) * 2 + ct) * 64 + lane];
+    const int64_t m = blk * 64 + ct * 32 + c;
+    {
+        const int64_t mm = m < a.M ? m : a.M - 1;
+        const int64_t ray = N::SAR ? (mm % a.ray_div) : (mm / a.ray_div);
+#pragma unroll
+        for (int ks = 0; ks < N::VKS; ++ks) {
+            view[ks] = a.view[(ray * N::VKS + ks) * 2 + h];
+            if (SAVE) a.act_view[((blk * N::VKS + ks) * 2 + ct) * 64 + lane] = view[ks];
+        }
+    }
+    __syncthreads();
+
+    WeightPipe pipe;
+    pipe.src = (const char*)a.wfwd;
+    pipe.slot_bytes = N::SLOT_KS * 1024;
+    pipe.ring = (LDS_AS char*)(smem + N::C_TOTAL * 4);
+    pipe.cur = 1;
+    pipe.wave = wave;
+    pipe.lane = lane;
+    pipe.template prefetch<N::DKS>(0);
+    pipe.template arrive<0>();
+
+    float hd_density[4], hd_colour[4], ln[2] = {0.f, 0.f};
+    bf16x8 xa[N::HKS], xb[N::HKS], none[1];
+    bf16x8 xw[N::WKS];
+    constexpr int HKS = N::HKS, HT = N::HT;
+    const float* bias = cst + N::C_BIAS;
+    // density_net0: enc -> X0 -> X1 -> X2 -> X3
+    fwd_layer<N, SAVE, HT, 0, N::DKS, HKS, true, EPI_PLAIN>(pipe, none, enc, xa, bias + 0 * N::HP, h, a.act[0], blk, ct, hd_density, ln);
+    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 1 * N::HP, h, a.act[1], blk, ct, hd_density, ln);
+    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 2 * N::HP, h, a.act[2], blk, ct, hd_density, ln);
+    fwd_layer<N, SAVE, HT, HKS, 0, HKS + N::DKS, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 3 * N::HP, h, a.act[3], blk, ct, hd_density, ln);
+    // density_net1: [X3 | enc] -> X4 -> ... -> X7 (trunk output)
+    fwd_layer<N, SAVE, HT, HKS, N::DKS, HKS, true, EPI_PLAIN>(pipe, xb, enc, xa, bias + 4 * N::HP, h, a.act[4], blk, ct, hd_density, ln);
+    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 5 * N::HP, h, a.act[5], blk, ct, hd_density, ln);
+    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 6 * N::HP, h, a.act[6], blk, ct, hd_density, ln);
+    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_TRUNK>(pipe, xa, none, xb, bias + 7 * N::HP, h, a.act[7], blk, ct, hd_density, ln);
+    // final_density as one more output tile on X7 (row 0), then rgb_net0 (no activation): X7 -> X8
+    fwd_layer<N, SAVE, 1, HKS, 0, HKS, false, EPI_HEAD>(pipe, xb, none, xw, cst + N::C_BIASD, h, nullptr, blk, ct, hd_density, ln);
+    fwd_layer<N, SAVE, HT, HKS, 0, HKS + N::VKS, false, EPI_PLAIN>(pipe, xb, none, xa, bias + 8 * N::HP, h, a.act[8], blk, ct, hd_colour, ln);
+    // rgb_net1: [X8 | view] -> X9 ; final_rgb (+ final_angle) as one output tile on X9 (rows 0..4)
+    fwd_layer<N, SAVE, N::WT, HKS, N::VKS, N::WKS, true, EPI_PLAIN>(pipe, xa, view, xw, cst + N::C_BIAS9, h, a.act[9], blk, ct, hd_colour, ln);
+    fwd_layer<N, SAVE, 1, N::WKS, 0, 0, false, EPI_HEAD>(pipe, xw, none, xa, cst + N::C_BIASH, h, nullptr, blk, ct, hd_colour, ln);
+
+    // outputs.  Lane half 0 holds rows 0..3 of a head tile, half 1 rows 4..7.
+    const float* sc = cst + N::C_SC;
+    float d = hd_density[0];
+    float mean = 0.f, rstd = 1.f;
+    if (N::SAR) {
+        const float s1 = ln[0] + __shfl_xor(ln[0], 32);
+        const float s2 = ln[1] + __shfl_xor(ln[1], 32);
+        mean = s1 * sc[8];
+        const float var = fmaxf(s2 * sc[8] - mean * mean, 0.f);
+        rstd = rsqrtf(var + sc[9]);
+        // sum_f w_f (gamma_f (x_f - mean) rstd + beta_f) + b = rstd (sum w gamma x - mean sum w gamma) + sum w beta + b;
+        // the head tile computed sum_f (w gamma)_f x_f (its bias row is 0 for SAR; b is folded into sc[7])
+        d = rstd * (d - mean * sc[6]) + sc[7];
+    }
+    const float ang1 = __shfl_xor(hd_colour[0], 32);      // row 4 lives in lane half 1
+    if (m < a.M && h == 0) {
+        a.raw_density[m] = d;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) a.raw_rgb[m * 3 + o] = sigmoid_f(hd_colour[o]);
+        if constexpr (N::SAR) {
+            a.raw_angle[m * 2 + 0] = sigmoid_f(hd_colour[3]);
+            a.raw_angle[m * 2 + 1] = sigmoid_f(ang1);
+            if (a.ln_stats != nullptr) {
+                a.ln_stats[m * 2 + 0] = mean;
+                a.ln_stats[m * 2 + 1] = rstd;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight packing.  One thread per 16-byte fragment element group.
+// Forward stream of one layer: pieces [nt][ks], lane (row r = l&31, half h): element j is
+// W[32 nt + r][col(16 ks + frag_feat(j,h))]; the padded k axis is [segment A | segment B].
+__global__ void pack_fwd_kernel(const float* __restrict__ W, int ld, int n_true, int a_true, int a_ks, int b_true,
+                                int b_ks, int NT, bf16x8* __restrict__ dst) {
+    const int KS = a_ks + b_ks;
+    const int total = NT * KS * 64;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int lane = i & 63;
+    const int ks = (i >> 6) % KS;
+    const int nt = (i >> 6) / KS;
+    const int n = nt * 32 + (lane & 31), h = lane >> 5;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = 0.f;
+        if (n < n_true) {
+            if (ks < a_ks) {
+                const int k = ks * 16 + frag_feat(j, h);
+                if (k < a_true) v = W[(int64_t)n * ld + k];
+            } else {
+                const int k = (ks - a_ks) * 16 + frag_feat(j, h);
+                if (k < b_true) v = W[(int64_t)n * ld + a_true + k];
+            }
+        }
+        o[j] = (__bf16)v;
+    }
+    dst[i] = o;
+}
+
+// Backward (transposed) stream of one layer: pieces [kt][s]; lane (row r, half h): element j is
+// W[16 s + frag_feat(j,h)][32 kt + r], rows limited to the first k_true input features.
+__global__ void pack_bwd_kernel(const float* __restrict__ W, int ld, int n_true, int k_true, int KT, int NS,
+                                bf16x8* __restrict__ dst) {
+    const int total = KT * NS * 64;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int lane = i & 63;
+    const int s = (i >> 6) % NS;
+    const int kt = (i >> 6) / NS;
+    const int k = kt * 32 + (lane & 31), h = lane >> 5;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = s * 16 + frag_feat(j, h);
+        o[j] = (__bf16)((k < k_true && n < n_true) ? W[(int64_t)n * ld + k] : 0.f);
+    }
+    dst[i] = o;
+}
+
+// As pack_bwd_kernel with a second matrix stacked below the first along the reduction axis.
+__global__ void pack_bwd2_kernel(const float* __restrict__ W, int ld, int n_true, const float* __restrict__ W2,
+                                 int ld2, int n2_true, int k_true, int KT, int NS, int NS2,
+                                 bf16x8* __restrict__ dst) {
+    const int NSS = NS + NS2;
+    const int total = KT * NSS * 64;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int lane = i & 63;
+    const int s = (i >> 6) % NSS;
+    const int kt = (i >> 6) / NSS;
+    const int k = kt * 32 + (lane & 31), h = lane >> 5;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = 0.f;
+        if (k < k_true) {
+            if (s < NS) {
+                const int n = s * 16 + frag_feat(j, h);
+                if (n < n_true) v = W[(int64_t)n * ld + k];
+            } else {
+                const int n = (s - NS) * 16 + frag_feat(j, h);
+                if (n < n2_true) v = W2[(int64_t)n * ld2 + k];
+            }
+        }
+        o[j] = (__bf16)v;
+    }
+    dst[i] = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// (a2)+(a3) fused: fenceposts -> conical frustum / cylinder Gaussian -> integrated positional
+// encoding, written straight in frag order (bf16).  One thread per (sample, lane half).
+//                                         reference: utils.py:130-137,162-164,91-100; util_modules.py:37-44
+__global__ void encode_frag_kernel(const float* __restrict__ t_vals, const float* __restrict__ origins,
+                                   const float* __restrict__ directions, const float* __restrict__ radii,
+                                   int64_t n_rays, int S, int ray_shape, int min_deg, int L, int DKS, int64_t nblk,
+                                   bf16x8* __restrict__ enc) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // ((blk*2 + ct)*64 + lane)
+    if (gid >= nblk * 128) return;
+    const int lane = (int)(gid & 63);
+    const int ct = (int)((gid >> 6) & 1);
+    const int64_t blk = gid >> 7;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t m = blk * 64 + ct * 32 + c;
+    const int64_t M = n_rays * S;
+    float mean[3] = {0.f, 0.f, 0.f}, cov[3] = {0.f, 0.f, 0.f};
+    const bool ok = m < M;
+    if (ok) {
+        const int64_t ray = m / S;
+        const int s = (int)(m - ray * S);
+        const float t0 = t_vals[ray * (S + 1) + s], t1 = t_vals[ray * (S + 1) + s + 1];
+        const float r = radii[ray];
+        float t_mean, t_var, r_var;
+        if (ray_shape == NERF_RAY_CONE) {
+            const float mu = (t0 + t1) / 2.f, hw = (t1 - t0) / 2.f;
+            const float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
+            const float denom = 3.f * mu2 + hw2;
+            t_mean = mu + (2.f * mu * hw2) / denom;
+            t_var = hw2 / 3.f - (float)(4.0 / 15.0) * ((hw4 * (12.f * mu2 - hw2)) / (denom * denom));
+            r_var = (r * r) * (mu2 / 4.f + (float)(5.0 / 12.0) * hw2 - (float)(4.0 / 15.0) * hw4 / denom);
+        } else {
+            t_mean = (t0 + t1) / 2.f;
+            r_var = (r * r) / 4.f;
+            t_var = ((t1 - t0) * (t1 - t0)) / 12.f;
+        }
+        float d[3], d2[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            d[k] = directions[ray * 3 + k];
+            d2[k] = d[k] * d[k];
+        }
+        const float dmag = (d2[0] + d2[1] + d2[2]) + 1e-10f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mean[k] = d[k] * t_mean + origins[ray * 3 + k];
+            cov[k] = t_var * d2[k] + r_var * (1.f - d2[k] / dmag);
+        }
+    }
+    const int F = 3 * L;
+    for (int ks = 0; ks < DKS; ++ks) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int f = ks * 16 + frag_feat(j, h);
+            float v = 0.f;
+            if (ok && f < 2 * F) {
+                const int k = f < F ? f : f - F;
+                const int l = k / 3, cc = k - 3 * l;
+                const float s1 = ldexpf(1.f, min_deg + l);
+                const float x = mean[cc] * s1 + (f < F ? 0.f : 1.5707963267948966f);
+                v = expf(-0.5f * (cov[cc] * (s1 * s1))) * sinf(x);
+            }
+            o[j] = (__bf16)v;
+        }
+        enc[((blk * DKS + ks) * 2 + ct) * 64 + lane] = o;
+    }
+}
+
+// View features [PE(dir) | dir] per ray in frag order: out[ray][ks][h] (bf16x8).
+//                                                  reference: util_modules.py:49, model.py:125-126
+__global__ void view_frag_kernel(const float* __restrict__ dirs, int64_t n_rays, int min_deg, int L, int VKS,
+                                 bf16x8* __restrict__ out) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_rays * VKS * 2) return;
+    const int h = (int)(gid & 1);
+    const int ks = (int)((gid >> 1) % VKS);
+    const int64_t ray = (gid >> 1) / VKS;
+    const int F = 3 * L;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int f = ks * 16 + frag_feat(j, h);
+        float v = 0.f;
+        if (f < 2 * F) {
+            const int k = f < F ? f : f - F;
+            const int l = k / 3, cc = k - 3 * l;
+            v = sinf(dirs[ray * 3 + cc] * ldexpf(1.f, min_deg + l) + (f < F ? 0.f : 1.5707963267948966f));
+        } else if (f < 2 * F + 3) {
+            v = dirs[ray * 3 + (f - 2 * F)];
+        }
+        o[j] = (__bf16)v;
+    }
+    out[gid] = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host side
+struct HostDims {
+    int D, V, H, W, sar;
+    int HT, WT, DKS, VKS;
+};
+
+static inline bool make_dims(const nerf_mlp_dims* d, HostDims* o) {
+    if (!d || d->enc_dim <= 0 || d->view_dim <= 0 || d->hidden <= 0 || d->width <= 0) return false;
+    o->D = d->enc_dim; o->V = d->view_dim; o->H = d->hidden; o->W = d->width; o->sar = d->sar;
+    o->HT = (d->hidden + 31) / 32; o->WT = (d->width + 31) / 32;
+    o->DKS = (d->enc_dim + 15) / 16; o->VKS = (d->view_dim + 15) / 16;
+    return true;
+}
+
+// supported compile-time geometries
+#define NERF_NET_LIST(X)        \
+    X(8, 4, 4, 2, false)        /* H=256 W=128 L=10 (64+128 configuration) */ \
+    X(8, 2, 4, 2, false)        /* H=256 W=64  L=10 (64+64 configuration)  */ \
+    X(8, 4, 6, 2, false)        /* H=256 W=128 L=16 (params.yaml nerf)     */ \
+    X(2, 1, 2, 2, false)        /* H=64  W<=32 L=4  (small test network)   */
+
+template <class N, bool SAVE>
+static int launch_fwd_t(const MlpFwdArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)mlp_fwd_kernel<N, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                N::FWD_LDS) != hipSuccess)
+            return NERF_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mlp_fwd_kernel<N, SAVE>), dim3((unsigned)(a.nblk / 4)), dim3(64 * kWaves), N::FWD_LDS, st, a);
+    return nerf_launch_status();
+}
+template <class N>
+static int launch_fwd(const MlpFwdArgs& a, hipStream_t st) {
+    return a.act[0] != nullptr ? launch_fwd_t<N, true>(a, st) : launch_fwd_t<N, false>(a, st);
+}
+
+extern "C" int nerf_mlp_sizes(const nerf_mlp_dims* dims, int64_t* wfwd_bytes, int64_t* wbwd_bytes,
+                              int64_t* consts_floats) {
+    HostDims d;
+    NERF_REQUIRE(make_dims(dims, &d));
+#define X(ht_, wt_, dks_, vks_, sar_)                                                              \
+    if (d.HT == ht_ && d.WT == wt_ && d.DKS == dks_ && d.VKS == vks_ && (d.sar != 0) == sar_) {   \
+        typedef Net<ht_, wt_, dks_, vks_, sar_> N;                                                 \
+        if (wfwd_bytes) *wfwd_bytes = (int64_t)N::FWD_PIECES * 1024;                               \
+        if (wbwd_bytes) *wbwd_bytes = (int64_t)N::BWD_PIECES * 1024;                               \
+        if (consts_floats) *consts_floats = N::C_TOTAL;                                            \
+        return NERF_OK;                                                                            \
+    }
+    NERF_NET_LIST(X)
+#undef X
+    return NERF_ERR_SIZE;
+}
+
+// weights[12], all fp32 [out,in]: 0-3 density_net0.{0,2,4,6}, 4-7 density_net1.{0,2,4,6}, 8 rgb_net0.0,
+// 9 rgb_net1.0, 10 the density head row [1,H] (SAR: final_density weight * LayerNorm gamma),
+// 11 the colour heads [3,W] (SAR: final_rgb and final_angle stacked, [5,W]).
+extern "C" int nerf_mlp_pack(const nerf_mlp_dims* dims, const float* const* weights, void* wfwd, void* wbwd,
+                             void* stream) {
+    HostDims d;
+    NERF_REQUIRE(make_dims(dims, &d) && weights && wfwd);
+    hipStream_t st = nerf_stream(stream);
+    bf16x8* f = (bf16x8*)wfwd;
+    bf16x8* b = (bf16x8*)wbwd;
+    const int HKS = 2 * d.HT;
+    auto pf = [&](const float* W, int ld, int n_true, int a_true, int a_ks, int b_true, int b_ks, int NT) {
+        const int total = NT * (a_ks + b_ks) * 64;
+        hipLaunchKernelGGL(pack_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W, ld, n_true, a_true, a_ks,
+                           b_true, b_ks, NT, f);
+        f += total;
+    };
+    auto pb = [&](const float* W, int ld, int n_true, int k_true, int KT, int NS) {
+        const int total = KT * NS * 64;
+        hipLaunchKernelGGL(pack_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W, ld, n_true, k_true, KT, NS,
+                           b);
+        b += total;
+    };
+    // second form: the reduction axis is [rows of W (NS k-steps) | rows of W2 (NS2 k-steps)]
+    auto pb2 = [&](const float* W, int ld, int n_true, const float* W2, int ld2, int n2_true, int k_true, int KT,
+                   int NS, int NS2) {
+        const int total = KT * (NS + NS2) * 64;
+        hipLaunchKernelGGL(pack_bwd2_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W, ld, n_true, W2, ld2,
+                           n2_true, k_true, KT, NS, NS2, b);
+        b += total;
+    };
+    for (int i = 0; i < 12; ++i) NERF_REQUIRE(weights[i] != nullptr);
+    pf(weights[0], d.D, d.H, 0, 0, d.D, d.DKS, d.HT);
+    for (int i = 1; i < 4; ++i) pf(weights[i], d.H, d.H, d.H, HKS, 0, 0, d.HT);
+    pf(weights[4], d.H + d.D, d.H, d.H, HKS, d.D, d.DKS, d.HT);
+    for (int i = 5; i < 8; ++i) pf(weights[i], d.H, d.H, d.H, HKS, 0, 0, d.HT);
+    pf(weights[10], d.H, 1, d.H, HKS, 0, 0, 1);                     // density head: one tile, row 0
+    pf(weights[8], d.H, d.H, d.H, HKS, 0, 0, d.HT);
+    pf(weights[9], d.H + d.V, d.W, d.H, HKS, d.V, d.VKS, d.WT);
+    pf(weights[11], d.W, d.sar ? 5 : 3, d.W, 2 * d.WT, 0, 0, 1);    // rgb (+angle) heads: one tile, rows 0..4
+    if (wbwd != nullptr) {
+        // consumption order of the backward chain: layer 9, 8, 7, ..., 1 (layer 0 needs no input gradient)
+        pb(weights[11], d.W, d.sar ? 5 : 3, d.W, d.WT, 1);               // heads^T: dX9 = Wh^T dZ, one k-step
+        pb(weights[9], d.H + d.V, d.W, d.H, d.HT, 2 * d.WT);
+        pb2(weights[8], d.H, d.H, weights[10], d.H, 1, d.H, d.HT, HKS, 1);  // [rgb_net0 ; density head]^T
+        for (int i = 7; i >= 5; --i) pb(weights[i], d.H, d.H, d.H, d.HT, HKS);
+        pb(weights[4], d.H + d.D, d.H, d.H, d.HT, HKS);
+        for (int i = 3; i >= 1; --i) pb(weights[i], d.H, d.H, d.H, d.HT, HKS);
+    }
+    return nerf_launch_status();
+}
+
+extern "C" int nerf_encode_frag(const float* t_vals, const float* origins, const float* directions,
+                                const float* radii, int64_t n_rays, int num_samples, int ray_shape, int min_deg,
+                                int max_deg, void* enc_frag, void* stream) {
+    if (n_rays == 0) return NERF_OK;
+    NERF_REQUIRE(t_vals && origins && directions && radii && enc_frag && n_rays > 0 && num_samples >= 1 &&
+                 max_deg > min_deg);
+    const int L = max_deg - min_deg;
+    const int DKS = (6 * L + 15) / 16;
+    const int64_t nblk = (n_rays * num_samples + 63) / 64;
+    hipLaunchKernelGGL(encode_frag_kernel, dim3(nerf_blocks(nblk * 128, 256)), dim3(256), 0, nerf_stream(stream),
+                       t_vals, origins, directions, radii, n_rays, num_samples, ray_shape, min_deg, L, DKS, nblk,
+                       (bf16x8*)enc_frag);
+    return nerf_launch_status();
+}
+
+extern "C" int nerf_view_frag(const float* dirs, int64_t n_rays, int min_deg, int max_deg, void* out, void* stream) {
+    if (n_rays == 0) return NERF_OK;
+    NERF_REQUIRE(dirs && out && n_rays > 0 && max_deg > min_deg);
+    const int L = max_deg - min_deg;
+    const int VKS = (6 * L + 3 + 15) / 16;
+    hipLaunchKernelGGL(view_frag_kernel, dim3(nerf_blocks(n_rays * VKS * 2, 256)), dim3(256), 0, nerf_stream(stream),
+                       dirs, n_rays, min_deg, L, VKS, (bf16x8*)out);
+    return nerf_launch_status();
+}
+
+extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* consts, const void* enc_frag,
+                            const void* view_frag, int64_t n_samples, int ray_div, int64_t n_rays,
+                            void* const* acts /* 11 pointers (X0..X9, view) or NULL */, float* raw_density,
+                            float* raw_rgb, float* raw_angle, float* ln_stats, void* stream) {
+    if (n_samples == 0) return NERF_OK;
+    HostDims d;
+    NERF_REQUIRE(make_dims(dims, &d) && wfwd && consts && enc_frag && view_frag && raw_density && raw_rgb);
+    NERF_REQUIRE(n_samples > 0 && ray_div > 0 && n_rays > 0);
+    if (d.sar) NERF_REQUIRE(raw_angle != nullptr);
+    MlpFwdArgs a;
+    a.wfwd = (const bf16x8*)wfwd;
+    a.consts = consts;
+    a.enc = (const bf16x8*)enc_frag;
+    a.view = (const bf16x8*)view_frag;
+    a.M = n_samples;
+    a.nblk = ((n_samples + 255) / 256) * 4;      // blocks of 64 samples, whole workgroups
+    a.ray_div = ray_div;
+    a.n_rays = (int)n_rays;
+    for (int i = 0; i < 10; ++i) a.act[i] = acts ? (bf16x8*)acts[i] : nullptr;
+    a.act_view = acts ? (bf16x8*)acts[10] : nullptr;
+    a.raw_density = raw_density;
+    a.raw_rgb = raw_rgb;
+    a.raw_angle = raw_angle;
+    a.ln_stats = ln_stats;
+#define X(ht_, wt_, dks_, vks_, sar_)                                                          \
+    if (d.HT == ht_ && d.WT == wt_ && d.DKS == dks_ && d.VKS == vks_ && (d.sar != 0) == sar_)  \
+        return launch_fwd<Net<ht_, wt_, dks_, vks_, sar_>>(a, nerf_stream(stream));
+    NERF_NET_LIST(X)
+#undef X
+    return NERF_ERR_SIZE;
+}

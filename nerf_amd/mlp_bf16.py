@@ -1,0 +1,141 @@
+"""Python side of the fused bf16 MFMA MLP (`csrc/mlp_bf16.hip`): weight packing, buffer
+management and the autograd hook-up of the forward / backward / weight-gradient kernels.
+
+Data never takes a detour through torch math here: torch only allocates device buffers and owns
+the fp32 master parameters (the reference's nn.Linear tensors, model.py:54-93)."""
+import ctypes
+from ctypes import POINTER, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+from . import _lib
+from ._lib import MlpDims, check, f32c, lib, ptr, stream
+
+_P = c_void_p
+_lib.register('nerf_mlp_sizes', c_int, [POINTER(MlpDims), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)])
+_lib.register('nerf_mlp_pack', c_int, [POINTER(MlpDims), POINTER(c_void_p), _P, _P, _P])
+_lib.register('nerf_encode_frag', c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P, _P])
+_lib.register('nerf_view_frag', c_int, [_P, c_int64, c_int, c_int, _P, _P])
+_lib.register('nerf_mlp_fwd', c_int, [POINTER(MlpDims), _P, _P, _P, _P, c_int64, c_int, c_int64, POINTER(c_void_p),
+                                      _P, _P, _P, _P, _P])
+
+STREAMED = (['density_net0.%d' % i for i in (0, 2, 4, 6)] + ['density_net1.%d' % i for i in (0, 2, 4, 6)]
+            + ['rgb_net0.0', 'rgb_net1.0'])
+RAY_SHAPES = {'cone': 0, 'cylinder': 1}
+
+
+def _raw(t):
+    """Device pointer of any contiguous tensor (byte buffers, bf16 fragments)."""
+    assert t.is_cuda and t.is_contiguous()
+    return c_void_p(t.data_ptr())
+
+
+class Packed:
+    """bf16 weight streams + fp32 constants of one model, valid until the next optimizer step."""
+
+    def __init__(self, model, need_bwd=True):
+        cfg = model.config
+        p = {k: v.detach() for k, v in model.named_parameters()}
+        dev = p['rgb_net0.0.weight'].device
+        self.sar = 'final_angle.0.weight' in p
+        H, W = cfg.hidden, cfg.num_samples
+        D = 6 * (cfg.max_deg - cfg.min_deg)
+        V = 3 + 6 * (cfg.viewdirs_max_deg - cfg.viewdirs_min_deg)
+        self.dims = MlpDims(D, V, H, W, int(self.sar))
+        self.H, self.W, self.D, self.V = H, W, D, V
+        self.HT, self.WT = (H + 31) // 32, (W + 31) // 32
+        self.DKS, self.VKS = (D + 15) // 16, (V + 15) // 16
+        HP, WP = 32 * self.HT, 32 * self.WT
+        nf, nb, nc = c_int64(), c_int64(), c_int64()
+        check(lib().nerf_mlp_sizes(ctypes.byref(self.dims), ctypes.byref(nf), ctypes.byref(nb), ctypes.byref(nc)))
+        self.wfwd = torch.empty(nf.value, dtype=torch.uint8, device=dev)
+        self.wbwd = torch.empty(nb.value, dtype=torch.uint8, device=dev) if need_bwd else None
+
+        # density head row and stacked colour heads (fp32 [out,in] like every streamed matrix)
+        if self.sar:
+            gamma, beta = p['final_density.0.weight'], p['final_density.0.bias']
+            wd, bd = p['final_density.1.weight'], p['final_density.1.bias']
+            self.head_density = (wd * gamma[None, :]).contiguous()
+            self.head_colour = torch.cat([p['final_rgb.0.weight'], p['final_angle.0.weight']], 0).contiguous()
+            head_bias = torch.cat([p['final_rgb.0.bias'], p['final_angle.0.bias']])
+        else:
+            wd, bd = p['final_density.0.weight'], p['final_density.0.bias']
+            self.head_density = wd.contiguous()
+            self.head_colour = p['final_rgb.0.weight'].contiguous()
+            head_bias = p['final_rgb.0.bias']
+        mats = [f32c(p[n + '.weight']) for n in STREAMED] + [f32c(self.head_density), f32c(self.head_colour)]
+        self._keep = mats
+        arr = (c_void_p * 12)(*[m.data_ptr() for m in mats])
+        check(lib().nerf_mlp_pack(ctypes.byref(self.dims), arr, _raw(self.wfwd),
+                                  _raw(self.wbwd) if need_bwd else None, stream()))
+
+        # fp32 constants block (layout: Net::C_* in mlp_bf16.hip)
+        c = torch.zeros(nc.value, dtype=torch.float32, device=dev)
+        for i, n in enumerate(STREAMED[:9]):
+            c[i * HP:i * HP + H] = p[n + '.bias']
+        o = 9 * HP
+        c[o:o + W] = p['rgb_net1.0.bias']
+        o += WP
+        if not self.sar:
+            c[o] = bd[0]
+        o += 32
+        c[o:o + head_bias.numel()] = head_bias
+        o += 32
+        if self.sar:
+            c[o + 6] = self.head_density.sum()
+            c[o + 7] = (wd[0] * beta).sum() + bd[0]
+            c[o + 8] = 1.0 / H
+            c[o + 9] = 1e-5
+        self.consts = c
+
+
+def packed_for(model, need_bwd=True):
+    pk = getattr(model, '_packed', None)
+    if pk is None or (need_bwd and pk.wbwd is None):
+        pk = Packed(model, need_bwd)
+        model._packed = pk
+    return pk
+
+
+def n_blocks(n_samples):
+    return ((n_samples + 255) // 256) * 4
+
+
+def encode_frag(t_vals, origins, directions, radii, ray_shape, min_deg, max_deg):
+    """(a2)+(a3): fenceposts -> Gaussians -> IPE, as bf16 fragments (uint8 buffer)."""
+    t_vals = f32c(t_vals)
+    n, s1 = t_vals.shape
+    S = s1 - 1
+    dks = (6 * (max_deg - min_deg) + 15) // 16
+    out = torch.empty(n_blocks(n * S) * dks * 2 * 1024, dtype=torch.uint8, device=t_vals.device)
+    check(lib().nerf_encode_frag(ptr(t_vals), ptr(f32c(origins).reshape(n, 3)), ptr(f32c(directions).reshape(n, 3)),
+                                 ptr(f32c(radii).reshape(n)), n, S, RAY_SHAPES[ray_shape], min_deg, max_deg,
+                                 _raw(out), stream()))
+    return out
+
+
+def view_frag(dirs, min_deg, max_deg):
+    dirs = f32c(dirs).reshape(-1, 3)
+    vks = (6 * (max_deg - min_deg) + 3 + 15) // 16
+    out = torch.empty(dirs.shape[0] * vks * 2 * 16, dtype=torch.uint8, device=dirs.device)
+    check(lib().nerf_view_frag(ptr(dirs), dirs.shape[0], min_deg, max_deg, _raw(out), stream()))
+    return out
+
+
+def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False):
+    """-> raw_density [M], raw_rgb [M,3], raw_angle [M,2] or None, acts (list of byte buffers) or None."""
+    dev = enc.device
+    nblk = n_blocks(n_samples)
+    raw_density = torch.empty(n_samples, device=dev)
+    raw_rgb = torch.empty(n_samples, 3, device=dev)
+    raw_angle = torch.empty(n_samples, 2, device=dev) if pk.sar else None
+    ln_stats = torch.empty(n_samples, 2, device=dev) if (pk.sar and save) else None
+    acts = arr = None
+    if save:
+        widths = [32 * pk.HT] * 9 + [32 * pk.WT, 16 * pk.VKS]
+        acts = [torch.empty(nblk * w * 128, dtype=torch.uint8, device=dev) for w in widths]
+        arr = (c_void_p * 11)(*[a.data_ptr() for a in acts])
+    check(lib().nerf_mlp_fwd(ctypes.byref(pk.dims), _raw(pk.wfwd), ptr(pk.consts), _raw(enc), _raw(view), n_samples,
+                             ray_div, n_rays, arr, ptr(raw_density), ptr(raw_rgb), ptr(raw_angle), ptr(ln_stats),
+                             stream()))
+    return raw_density, raw_rgb, raw_angle, acts, ln_stats

@@ -95,6 +95,9 @@ class _RenderModule(nn.Module):
         return self
 
     def eval(self):
+        # As upstream (model.py:209-216): nn.Module.eval() calls self.train(False), which restores
+        # `randomized = init_randomized`, so eval() does NOT switch the sampling jitter off.  Set
+        # `model.randomized = False` (or config.randomized) for a deterministic render.
         self.randomized = False
         return super().eval()
 

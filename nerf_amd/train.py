@@ -1,0 +1,82 @@
+"""Training-step driver for the ray-sharded render path: chunked forward/backward over a batch of
+rays with gradient accumulation, one flat-bucket all-reduce of the weight gradients across ranks,
+one optimizer step.  (The reference's `training_step`, model.py:185-191, processes the whole batch
+at once on one device.)"""
+import torch
+
+from .utils import Rays, namedtuple_map
+
+
+def synthetic_rays(n, device, seed=0, normalize=True):
+    """Synthetic Blender-like rays: origins near (0,0,4), unit directions, near=2, far=6."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    o = 0.1 * torch.randn(n, 3, generator=g) + torch.tensor([0., 0., 4.])
+    d = torch.randn(n, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    if not normalize:
+        d = d * (1.0 + 0.2 * torch.rand(n, 1, generator=g))
+    v = d / d.norm(dim=-1, keepdim=True)
+    rays = Rays(o, d, v, torch.full((n, 1), 0.005), torch.ones(n, 1), torch.full((n, 1), 2.), torch.full((n, 1), 6.))
+    pixels = torch.rand(n, 3, generator=g)
+    return namedtuple_map(lambda t: t.to(device), rays), pixels.to(device)
+
+
+def flat_grads(params):
+    """One contiguous fp32 bucket holding every gradient (a single collective per step)."""
+    return torch.cat([p.grad.reshape(-1) for p in params])
+
+
+def scatter_flat_grads(params, flat):
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p))
+        off += n
+
+
+def allreduce_grads(params, world_size):
+    """SUM-all-reduce of the flattened gradient bucket (RCCL on GPUs, gloo on CPU)."""
+    if world_size <= 1:
+        return
+    import torch.distributed as dist
+    flat = flat_grads(params)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    scatter_flat_grads(params, flat)
+
+
+def shard_range(n, rank, world_size):
+    """Contiguous, near-equal ray shard of rank `rank`."""
+    base, rem = divmod(n, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def nerf_train_step(model, rays, pixels, optimizer, chunk=8192, world_size=1, global_mask_sum=None, scheduler=None):
+    """fwd + bwd (+ all-reduce) + optimizer step on this rank's rays.
+
+    The loss is sum(mask * err^2) / sum(mask) over the GLOBAL batch (util_modules.py:65), so each
+    chunk contributes its masked squared-error sum divided by the global mask sum; gradients then
+    add up across chunks and ranks."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    n = rays.origins.shape[0]
+    if global_mask_sum is None:
+        global_mask_sum = rays.lossmult.sum() * world_size
+    optimizer.zero_grad(set_to_none=False)
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    total = torch.zeros((), device=rays.origins.device)
+    cwd = model.loss_function.coarse_weight_decay
+    for i in range(0, n, chunk):
+        r = namedtuple_map(lambda t: t[i:i + chunk], rays)
+        rgb = model(r)[0]
+        sq = (r.lossmult * (rgb - pixels[i:i + chunk][None]) ** 2).sum(dim=(1, 2)) / global_mask_sum
+        loss = cwd * sq[:-1].sum() + sq[-1]
+        loss.backward()
+        total += loss.detach()
+    allreduce_grads(params, world_size)
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    model._weights_changed()
+    return total
