@@ -208,6 +208,24 @@ int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* const
                  const void* view_frag, int64_t n_samples, int ray_div, int64_t n_rays, void* const* acts,
                  float* raw_density, float* raw_rgb, float* raw_angle, float* ln_stats, void* stream);
 
+/* Backward chain of the fused MLP: from dL/d raw_density [M], dL/d raw_rgb [M,3] (w.r.t. the
+ * post-sigmoid output; raw_rgb is that saved output) through every layer, writing dL/d(layer
+ * pre-activation) as bf16 fragments: dys[0..9] for the ten streamed layers, dys[10] / dys[11] the
+ * 32-row head tiles (colour heads / density head) the weight-gradient kernel consumes.  acts are
+ * the buffers nerf_mlp_fwd saved.  NeRF heads only (SAR trains on the fp32 path).
+ *                              reference: autograd of model.py:117-132 (aten::mm, threshold_backward) */
+int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, int64_t n_samples, const float* g_density,
+                 const float* g_rgb, const float* g_angle, const float* raw_rgb, const float* raw_angle,
+                 const float* ln_stats, void* const* acts, void* const* dys, void* stream);
+
+/* Weight / bias gradient of one linear layer from fragments: G[n, col0 + k] += sum_m dY[m,n] X[m,k]
+ * (n < n_true, k < k_true; G is fp32 [n_true, ld]) and gb[n] += sum_m dY[m,n] (gb nullable).
+ * n_feat / k_feat: padded feature counts of the two fragment buffers (multiples of 32, <= 256).
+ * Accumulates with fp32 atomics: zero G / gb first for a fresh gradient.
+ *                              reference: autograd of nn.Linear (aten::mm of dY^T and X, aten::sum) */
+int nerf_mlp_wgrad(const void* dy_frag, int n_feat, const void* x_frag, int k_feat, int64_t n_samples,
+                   float* G, int ld, int col0, int n_true, int k_true, float* gb, int grid_hint, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

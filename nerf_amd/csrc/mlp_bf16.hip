@@ -63,7 +63,7 @@ struct Net {
     static constexpr int C_TOTAL = C_SC + 16;
     static constexpr int SLOT_KS = HKS + (DKS > VKS ? DKS : VKS);
     static constexpr int FWD_LDS = C_TOTAL * 4 + 2 * SLOT_KS * 1024;
-    static constexpr int BWD_SLOT_KS = HKS > WKS ? HKS : WKS;
+    static constexpr int BWD_SLOT_KS = (HKS + 1) > WKS ? (HKS + 1) : WKS;
     static constexpr int BWD_LDS = C_TOTAL * 4 + 2 * BWD_SLOT_KS * 1024;
     // pieces (1 KiB) in the packed streams
     // forward: L0, L1-3, L4, L5-7, density head tile, L8, L9, rgb/angle head tile
@@ -281,6 +281,288 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
             if (a.ln_stats != nullptr) {
                 a.ln_stats[m * 2 + 0] = mean;
                 a.ln_stats[m * 2 + 1] = rstd;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward chain: dY_i = (W_{i+1}^T dY_{i+1}) * [X_i > 0], all layers in one launch, same register
+// chaining as the forward pass (the fp32 accumulator tile of one layer's input gradient is the B
+// operand of the next product).  Reads the saved bf16 activations only for the ReLU masks, writes
+// every dY as bf16 frags for the weight-gradient kernel.
+struct MlpBwdArgs {
+    const bf16x8* wbwd;        // packed transposed weight stream
+    int64_t M, nblk;
+    const float* g_density;    // [M]   dL/d raw_density
+    const float* g_rgb;        // [M,3] dL/d raw_rgb (post-sigmoid output)
+    const float* g_angle;      // [M,2] (SAR)
+    const float* raw_rgb;      // [M,3] saved sigmoid outputs
+    const float* raw_angle;    // [M,2]
+    const float* ln_stats;     // [M,2] (SAR)
+    const bf16x8* act[10];     // X0..X9
+    bf16x8* dy[10];            // dY0..dY9
+    bf16x8* dy_hd;             // [nblk][2][2][64] head tile of dL/d(pre-sigmoid colour/angle outputs), rows 0..4
+    bf16x8* dy_dens;           // [nblk][2][2][64] head tile of dL/d raw_density (row 0)
+};
+
+// mask = all-ones where the (non-negative) saved activation is non-zero
+__device__ __forceinline__ bf16x8 relu_mask_apply(bf16x8 g, bf16x8 x) {
+    const s16x8 xs = __builtin_bit_cast(s16x8, x);
+    const s16x8 m = ((s16x8)(0) - xs) >> 15;
+    return __builtin_bit_cast(bf16x8, (s16x8)(__builtin_bit_cast(s16x8, g) & m));
+}
+
+// One backward layer: NT output tiles (features of the layer INPUT), reduction over KS_M k-steps of
+// `gm` (the layer's dY) then KS_E of `ge`.  MASKED: multiply by [act > 0] with `act` the saved input.
+template <class N, int NT, int KS_M, int KS_E, int NEXT_KS, bool MASKED, int KM, int KE, int KO>
+__device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[KM], const bf16x8 (&ge)[KE],
+                                          bf16x8 (&out)[KO], const bf16x8* act, bf16x8* dy, int64_t blk, int ct) {
+    constexpr int KS = KS_M + KS_E;
+    const int lane = pipe.lane;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (nt + 1 < NT) pipe.template prefetch<KS>(pipe.cur ^ 1);
+        else pipe.template prefetch<NEXT_KS>(pipe.cur ^ 1);
+        bf16x8 xk[2];
+        if (MASKED) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) xk[s] = act[((blk * (2 * NT) + 2 * nt + s) * 2 + ct) * 64 + lane];
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 a = pipe.piece(ks);
+            const bf16x8 b = ks < KS_M ? gm[ks < KS_M ? ks : 0] : ge[ks >= KS_M ? ks - KS_M : 0];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (__bf16)acc[8 * s + j];
+            if (MASKED) o = relu_mask_apply(o, xk[s]);
+            out[2 * nt + s] = o;
+            dy[((blk * (2 * NT) + 2 * nt + s) * 2 + ct) * 64 + lane] = o;
+        }
+        pipe.template arrive<2>();
+    }
+}
+
+template <class N>
+__global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
+    static_assert(!N::SAR, "the SAR head's backward chain is not instantiated");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int ct = wave & 1;
+    const int64_t blk = (int64_t)blockIdx.x * 4 + (wave >> 1);
+    const int64_t m = blk * 64 + ct * 32 + c;
+    const bool ok = m < a.M;
+
+    // gradient w.r.t. the pre-sigmoid head outputs and the raw density, as one-k-step B operands:
+    // rows 0..3 of a head tile are elements 0..3 of lane half 0, row 4 is element 0 of lane half 1.
+    bf16x8 dz, dd, zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dz[j] = dd[j] = zero[j] = (__bf16)0.f;
+    if (ok && h == 0) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float sg = a.raw_rgb[m * 3 + o];
+            dz[o] = (__bf16)(a.g_rgb[m * 3 + o] * sg * (1.f - sg));
+        }
+        dd[0] = (__bf16)a.g_density[m];
+    }
+    // head tiles for the weight-gradient kernel (32 rows = two k-steps, the second all zero)
+    a.dy_hd[((blk * 2 + 0) * 2 + ct) * 64 + lane] = dz;
+    a.dy_hd[((blk * 2 + 1) * 2 + ct) * 64 + lane] = zero;
+    a.dy_dens[((blk * 2 + 0) * 2 + ct) * 64 + lane] = dd;
+    a.dy_dens[((blk * 2 + 1) * 2 + ct) * 64 + lane] = zero;
+
+    WeightPipe pipe;
+    pipe.src = (const char*)a.wbwd;
+    pipe.slot_bytes = N::BWD_SLOT_KS * 1024;
+    pipe.ring = (LDS_AS char*)smem;
+    pipe.cur = 1;
+    pipe.wave = wave;
+    pipe.lane = lane;
+    pipe.template prefetch<1>(0);
+    pipe.template arrive<0>();
+
+    constexpr int HKS = N::HKS, HT = N::HT, WKS = N::WKS;
+    bf16x8 ga[HKS], gb[HKS], gw[WKS], none[1], dzv[1] = {dz}, ddv[1] = {dd};
+    // heads^T: dX9 = Wh^T dz, masked by X9 > 0 -> dY9
+    bwd_layer<N, N::WT, 1, 0, WKS, true>(pipe, dzv, none, gw, a.act[9], a.dy[9], blk, ct);
+    // rgb_net1^T (rows of X8 only): dY8 = W9[:, :H]^T dY9   (rgb_net0 has no activation)
+    bwd_layer<N, HT, WKS, 0, HKS + 1, false>(pipe, gw, none, ga, nullptr, a.dy[8], blk, ct);
+    // [rgb_net0 ; density head]^T: dX7 = W8^T dY8 + wd^T dd, masked by X7 > 0 -> dY7
+    bwd_layer<N, HT, HKS, 1, HKS, true>(pipe, ga, ddv, gb, a.act[7], a.dy[7], blk, ct);
+    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, gb, none, ga, a.act[6], a.dy[6], blk, ct);
+    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, ga, none, gb, a.act[5], a.dy[5], blk, ct);
+    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, gb, none, ga, a.act[4], a.dy[4], blk, ct);
+    // density_net1.0^T (rows of X3 only; the encoding needs no gradient)
+    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, ga, none, gb, a.act[3], a.dy[3], blk, ct);
+    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, gb, none, ga, a.act[2], a.dy[2], blk, ct);
+    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, ga, none, gb, a.act[1], a.dy[1], blk, ct);
+    bwd_layer<N, HT, HKS, 0, 0, true>(pipe, gb, none, ga, a.act[0], a.dy[0], blk, ct);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient: G[n][col0 + k] += sum_m dY[m][n] X[m][k], gb[n] += sum_m dY[m][n].
+// Both operands arrive as frags (sample on the lane, features in registers) but the reduction runs
+// over samples, so each 64-sample block is laid out in LDS as a [sample][feature] image (8-byte
+// units XOR-swizzled so that both the fill and the transposed reads spread over the banks) and read
+// back with ds_read_b64_tr_b16: lane = feature, registers = 4 consecutive samples.
+// HBM-bound (each operand byte is used for 2*256 FLOP): one workgroup of 4 waves per CU, persistent
+// over blocks, the next block's 16 loads per thread in flight while the current one is multiplied.
+struct WgradArgs {
+    const bf16x8* dy;          // [nblk][2*NT][2][64]
+    const bf16x8* x;           // [nblk][2*KT][2][64]
+    int64_t nblk;
+    int NT, KT, WN, WK;
+    float* G;                  // fp32 [n_true][ld]
+    int ld, col0, n_true, k_true;
+    float* gb;                 // fp32 [n_true] or NULL
+};
+
+__device__ __forceinline__ unsigned img_off(int row, int cb, unsigned row_bytes) {
+    // cb: byte column (multiple of 8).  64-byte chunks swizzled by row&3 (when the row has >= 4 chunks),
+    // 8-byte units inside a chunk by (row>>2)&7.
+    const unsigned nchunk = row_bytes >> 6;
+    unsigned chunk = (unsigned)cb >> 6;
+    if ((nchunk & (nchunk - 1)) == 0) chunk ^= (row & 3) & (nchunk - 1);
+    const unsigned unit = (((unsigned)cb >> 3) & 7) ^ ((row >> 2) & 7);
+    return row * row_bytes + (chunk << 6) + (unit << 3);
+}
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// ds_read_b64_tr_b16 through the compiler's builtin, so its LDS wait is tracked like any other read
+__device__ __forceinline__ bf16x4 lds_tr_read(LDS_AS const char* p) {
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)p));
+}
+
+template <int NTW, int KTW>
+__global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / a.WK, wk = wave % a.WK;
+    const unsigned rb_y = a.NT * 64, rb_x = a.KT * 64;            // image row bytes (32 features * 2 B per tile)
+    LDS_AS char* img_y = (LDS_AS char*)smem;
+    LDS_AS char* img_x = img_y + 64 * rb_y;
+    const int pieces_y = a.NT * 4, pieces_x = a.KT * 4;           // 1 KiB pieces per block: (2*NT k-steps) x 2 column tiles
+    const int per_thread = (pieces_y + pieces_x + 3) / 4;         // pieces are dealt round-robin to the 4 waves
+    bf16x8 stage[16];
+
+    f32x16 acc[NTW][KTW];
+    f32x16 accb[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    auto load_block = [&](int64_t b) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int p = i * 4 + wave;
+            if (i < per_thread && p < pieces_y + pieces_x)
+                stage[i] = p < pieces_y ? a.dy[(b * pieces_y + p) * 64 + lane] : a.x[(b * pieces_x + (p - pieces_y)) * 64 + lane];
+        }
+    };
+    auto store_block = [&]() {
+        const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int p = i * 4 + wave;
+            if (i < per_thread && p < pieces_y + pieces_x) {
+                const bool isy = p < pieces_y;
+                const int q = isy ? p : p - pieces_y;              // piece = (k-step ks, column tile ct)
+                const int ks = q >> 1, ct = q & 1;
+                const int row = ct * 32 + c;
+                const int cb = 32 * ks + 8 * h;
+                LDS_AS char* img = isy ? img_y : img_x;
+                const unsigned rb = isy ? rb_y : rb_x;
+                const bf16x4 lo = __builtin_shufflevector(stage[i], stage[i], 0, 1, 2, 3);
+                const bf16x4 hi = __builtin_shufflevector(stage[i], stage[i], 4, 5, 6, 7);
+                *(LDS_AS bf16x4*)(img + img_off(row, cb, rb)) = lo;
+                *(LDS_AS bf16x4*)(img + img_off(row, cb + 16, rb)) = hi;
+            }
+        }
+    };
+    // operand (32 features starting at f0, 16 samples starting at s0): lane = feature, 8 consecutive samples
+    auto read_operand = [&](LDS_AS const char* img, unsigned rb, int f0, int s0) -> bf16x8 {
+        const int g = lane >> 4, i = lane & 15;
+        const int row = s0 + 8 * (g >> 1) + (i >> 2);
+        const int cb = f0 * 2 + 32 * (g & 1) + 8 * (i & 3);
+        const bf16x4 lo = lds_tr_read(img + img_off(row, cb, rb));
+        const bf16x4 hi = lds_tr_read(img + img_off(row + 4, cb, rb));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    int64_t b = blockIdx.x;
+    if (b < a.nblk) load_block(b);
+    for (; b < a.nblk; b += gridDim.x) {
+        __syncthreads();                       // everyone finished reading the previous image
+        store_block();
+        __syncthreads();
+        if (b + gridDim.x < a.nblk) load_block(b + gridDim.x);
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+            bf16x8 A[NTW], B[KTW];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                const int nt = wn * NTW + i;
+                A[i] = read_operand(img_y, rb_y, (nt < a.NT ? nt : 0) * 32, ms * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < KTW; ++j) {
+                const int kt = wk * KTW + j;
+                B[j] = read_operand(img_x, rb_x, (kt < a.KT ? kt : 0) * 32, ms * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+#pragma unroll
+                for (int j = 0; j < KTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc[i][j], 0, 0, 0);
+                if (a.gb != nullptr && wk == 0) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], ones, accb[i], 0, 0, 0);
+            }
+        }
+    }
+    // flush: accumulator element r of lane l is dW[row n = tile*32 + acc_row(r, l>>5)][col k = tile*32 + (l&31)]
+    const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int nt = wn * NTW + i;
+        if (nt >= a.NT) continue;
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) {
+            const int kt = wk * KTW + j;
+            if (kt >= a.KT) continue;
+            const int k = kt * 32 + c;
+            if (k >= a.k_true) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nt * 32 + acc_row(r, h);
+                if (n < a.n_true) atomicAdd(&a.G[(int64_t)n * a.ld + a.col0 + k], acc[i][j][r]);
+            }
+        }
+        if (a.gb != nullptr && wk == 0 && c == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nt * 32 + acc_row(r, h);
+                if (n < a.n_true) atomicAdd(&a.gb[n], accb[i][r]);
             }
         }
     }
@@ -580,7 +862,7 @@ extern "C" int nerf_encode_frag(const float* t_vals, const float* origins, const
                  max_deg > min_deg);
     const int L = max_deg - min_deg;
     const int DKS = (6 * L + 15) / 16;
-    const int64_t nblk = (n_rays * num_samples + 63) / 64;
+    const int64_t nblk = ((n_rays * num_samples + 255) / 256) * 4;   // whole workgroups of the MLP kernels; padding is zero
     hipLaunchKernelGGL(encode_frag_kernel, dim3(nerf_blocks(nblk * 128, 256)), dim3(256), 0, nerf_stream(stream),
                        t_vals, origins, directions, radii, n_rays, num_samples, ray_shape, min_deg, L, DKS, nblk,
                        (bf16x8*)enc_frag);
@@ -626,5 +908,100 @@ extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const f
         return launch_fwd<Net<ht_, wt_, dks_, vks_, sar_>>(a, nerf_stream(stream));
     NERF_NET_LIST(X)
 #undef X
+    return NERF_ERR_SIZE;
+}
+
+template <class N>
+static int launch_bwd(const MlpBwdArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    constexpr int lds = 2 * N::BWD_SLOT_KS * 1024;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)mlp_bwd_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess)
+            return NERF_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mlp_bwd_kernel<N>), dim3((unsigned)(a.nblk / 4)), dim3(64 * kWaves), lds, st, a);
+    return nerf_launch_status();
+}
+
+extern "C" int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, int64_t n_samples, const float* g_density,
+                            const float* g_rgb, const float* g_angle, const float* raw_rgb, const float* raw_angle,
+                            const float* ln_stats, void* const* acts, void* const* dys /* 12: dY0..dY9, colour head tile,
+                            density head tile */, void* stream) {
+    if (n_samples == 0) return NERF_OK;
+    HostDims d;
+    NERF_REQUIRE(make_dims(dims, &d) && wbwd && g_density && g_rgb && raw_rgb && acts && dys && n_samples > 0);
+    if (d.sar) return NERF_ERR_SIZE;   // SAR heads train on the fp32 path
+    MlpBwdArgs a;
+    a.wbwd = (const bf16x8*)wbwd;
+    a.M = n_samples;
+    a.nblk = ((n_samples + 255) / 256) * 4;
+    a.g_density = g_density; a.g_rgb = g_rgb; a.g_angle = g_angle;
+    a.raw_rgb = raw_rgb; a.raw_angle = raw_angle; a.ln_stats = ln_stats;
+    for (int i = 0; i < 10; ++i) {
+        NERF_REQUIRE(acts[i] && dys[i]);
+        a.act[i] = (const bf16x8*)acts[i];
+        a.dy[i] = (bf16x8*)dys[i];
+    }
+    NERF_REQUIRE(dys[10] && dys[11]);
+    a.dy_hd = (bf16x8*)dys[10];
+    a.dy_dens = (bf16x8*)dys[11];
+#define X(ht_, wt_, dks_, vks_, sar_)                                                            \
+    if (!sar_ && d.HT == ht_ && d.WT == wt_ && d.DKS == dks_ && d.VKS == vks_ && d.sar == 0)      \
+        return launch_bwd<Net<ht_, wt_, dks_, vks_, false>>(a, nerf_stream(stream));
+    NERF_NET_LIST(X)
+#undef X
+    return NERF_ERR_SIZE;
+}
+
+template <int NTW, int KTW>
+static int launch_wgrad(const WgradArgs& a, unsigned grid, size_t lds, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)mlp_wgrad_kernel<NTW, KTW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                128 * 1024) != hipSuccess)
+            return NERF_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, KTW>), dim3(grid), dim3(256), lds, st, a);
+    return nerf_launch_status();
+}
+
+// G[n_true, ld] (+= at column col0, k_true columns) and gb[n_true] (nullable) accumulate
+// dY^T X over n_samples rows; dy_frag has n_feat features (multiple of 32, <= 256), x_frag k_feat
+// features (multiple of 16, <= 256; a trailing half tile is zero-extended).
+extern "C" int nerf_mlp_wgrad(const void* dy_frag, int n_feat, const void* x_frag, int k_feat, int64_t n_samples,
+                              float* G, int ld, int col0, int n_true, int k_true, float* gb, int grid_hint,
+                              void* stream) {
+    if (n_samples == 0) return NERF_OK;
+    NERF_REQUIRE(dy_frag && x_frag && G && n_samples > 0 && n_feat > 0 && k_feat > 0 && n_feat % 32 == 0 &&
+                 k_feat % 32 == 0 && n_feat <= 256 && k_feat <= 256 && n_true <= n_feat && k_true <= k_feat);
+    WgradArgs a;
+    a.dy = (const bf16x8*)dy_frag;
+    a.x = (const bf16x8*)x_frag;
+    a.nblk = ((n_samples + 255) / 256) * 4;
+    a.NT = n_feat / 32;
+    a.KT = k_feat / 32;
+    a.WN = a.NT >= 4 ? 4 : (a.NT >= 2 ? 2 : 1);
+    a.WK = 4 / a.WN;
+    a.G = G; a.ld = ld; a.col0 = col0; a.n_true = n_true; a.k_true = k_true; a.gb = gb;
+    const int ntw = (a.NT + a.WN - 1) / a.WN, ktw = (a.KT + a.WK - 1) / a.WK;
+    unsigned grid = grid_hint > 0 ? (unsigned)grid_hint : 256u;
+    if ((int64_t)grid > a.nblk) grid = (unsigned)a.nblk;
+    const size_t lds = (size_t)64 * 64 * (a.NT + a.KT);
+    hipStream_t st = nerf_stream(stream);
+    if (ntw <= 1) {
+        if (ktw <= 1) return launch_wgrad<1, 1>(a, grid, lds, st);
+        if (ktw <= 2) return launch_wgrad<1, 2>(a, grid, lds, st);
+        if (ktw <= 4) return launch_wgrad<1, 4>(a, grid, lds, st);
+        return launch_wgrad<1, 8>(a, grid, lds, st);
+    }
+    if (ntw <= 2) {
+        if (ktw <= 1) return launch_wgrad<2, 1>(a, grid, lds, st);
+        if (ktw <= 2) return launch_wgrad<2, 2>(a, grid, lds, st);
+        if (ktw <= 4) return launch_wgrad<2, 4>(a, grid, lds, st);
+        return launch_wgrad<2, 8>(a, grid, lds, st);
+    }
     return NERF_ERR_SIZE;
 }

@@ -19,6 +19,10 @@ _lib.register('nerf_view_frag', c_int, [_P, c_int64, c_int, c_int, _P, _P])
 _lib.register('nerf_mlp_fwd', c_int, [POINTER(MlpDims), _P, _P, _P, _P, c_int64, c_int, c_int64, POINTER(c_void_p),
                                       _P, _P, _P, _P, _P])
 
+_lib.register('nerf_mlp_bwd', c_int, [POINTER(MlpDims), _P, c_int64, _P, _P, _P, _P, _P, _P, POINTER(c_void_p),
+                                      POINTER(c_void_p), _P])
+_lib.register('nerf_mlp_wgrad', c_int, [_P, c_int, _P, c_int, c_int64, _P, c_int, c_int, c_int, c_int, _P, c_int, _P])
+
 STREAMED = (['density_net0.%d' % i for i in (0, 2, 4, 6)] + ['density_net1.%d' % i for i in (0, 2, 4, 6)]
             + ['rgb_net0.0', 'rgb_net1.0'])
 RAY_SHAPES = {'cone': 0, 'cylinder': 1}
@@ -139,3 +143,83 @@ def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False):
                              ray_div, n_rays, arr, ptr(raw_density), ptr(raw_rgb), ptr(raw_angle), ptr(ln_stats),
                              stream()))
     return raw_density, raw_rgb, raw_angle, acts, ln_stats
+
+
+def mlp_backward(pk, acts, n_samples, g_density, g_rgb, raw_rgb):
+    """Backward chain -> list of 12 dY fragment buffers (dY0..dY9, colour head tile, density head tile)."""
+    dev = g_density.device
+    nblk = n_blocks(n_samples)
+    widths = [32 * pk.HT] * 9 + [32 * pk.WT, 32, 32]
+    dys = [torch.empty(nblk * w * 128, dtype=torch.uint8, device=dev) for w in widths]
+    a_arr = (c_void_p * 11)(*[a.data_ptr() for a in acts])
+    d_arr = (c_void_p * 12)(*[d.data_ptr() for d in dys])
+    check(lib().nerf_mlp_bwd(ctypes.byref(pk.dims), _raw(pk.wbwd), n_samples, ptr(f32c(g_density).reshape(-1)),
+                             ptr(f32c(g_rgb).reshape(-1, 3)), None, ptr(raw_rgb), None, None, a_arr, d_arr, stream()))
+    return dys
+
+
+def _wgrad(dy, n_feat, x, k_feat, n_samples, G, col0, n_true, k_true, gb):
+    check(lib().nerf_mlp_wgrad(_raw(dy), n_feat, _raw(x), k_feat, n_samples, ptr(G), G.stride(0), col0, n_true, k_true,
+                               ptr(gb), 0, stream()))
+
+
+def mlp_weight_grads(pk, acts, dys, encf, n_samples, grads):
+    """Accumulate all weight / bias gradients into `grads` (name -> zero-initialised or running fp32 tensor)."""
+    H, W, D, V = pk.H, pk.W, pk.D, pk.V
+    HP, WP = 32 * pk.HT, 32 * pk.WT
+    DP, VP = 16 * pk.DKS, 16 * pk.VKS
+    g = lambda n: (grads[n + '.weight'], grads[n + '.bias'])
+    M = n_samples
+    # density_net0
+    w, b = g('density_net0.0'); _wgrad(dys[0], HP, encf, DP, M, w, 0, H, D, b)
+    for l, i in ((1, 2), (2, 4), (3, 6)):
+        w, b = g('density_net0.%d' % i); _wgrad(dys[l], HP, acts[l - 1], HP, M, w, 0, H, H, b)
+    # density_net1 (first layer: [X3 | enc])
+    w, b = g('density_net1.0')
+    _wgrad(dys[4], HP, acts[3], HP, M, w, 0, H, H, b)
+    _wgrad(dys[4], HP, encf, DP, M, w, H, H, D, None)
+    for l, i in ((5, 2), (6, 4), (7, 6)):
+        w, b = g('density_net1.%d' % i); _wgrad(dys[l], HP, acts[l - 1], HP, M, w, 0, H, H, b)
+    w, b = g('final_density.0'); _wgrad(dys[11], 32, acts[7], HP, M, w, 0, 1, H, b)
+    w, b = g('rgb_net0.0'); _wgrad(dys[8], HP, acts[7], HP, M, w, 0, H, H, b)
+    w, b = g('rgb_net1.0')
+    _wgrad(dys[9], WP, acts[8], HP, M, w, 0, W, H, b)
+    _wgrad(dys[9], WP, acts[10], VP, M, w, H, W, V, None)
+    w, b = g('final_rgb.0'); _wgrad(dys[10], 32, acts[9], WP, M, w, 0, 3, W, b)
+
+
+PARAM_NAMES = [n + s for n in STREAMED + ['final_density.0', 'final_rgb.0'] for s in ('.weight', '.bias')]
+
+
+class _MlpNerf(torch.autograd.Function):
+    """raw_density [M,1], raw_rgb [M,3] = MLP(enc frags, view frags); gradients flow to the 24 parameters."""
+
+    @staticmethod
+    def forward(ctx, model, encf, viewf, n_samples, ray_div, n_rays, *params):
+        need_grad = any(ctx.needs_input_grad[6:])
+        pk = packed_for(model, need_bwd=need_grad)
+        d, rgb, _, acts, _ = mlp_forward(pk, encf, viewf, n_samples, ray_div, n_rays, save=need_grad)
+        ctx.pk, ctx.acts, ctx.encf, ctx.n = pk, acts, encf, n_samples
+        ctx.shapes = [(p.shape, p.device) for p in params]
+        ctx.save_for_backward(rgb)
+        return d.reshape(-1, 1), rgb
+
+    @staticmethod
+    def backward(ctx, g_density, g_rgb):
+        (rgb,) = ctx.saved_tensors
+        pk = ctx.pk
+        dys = mlp_backward(pk, ctx.acts, ctx.n, g_density, g_rgb, rgb)
+        grads = {n: torch.zeros(shape, device=dev, dtype=torch.float32) for n, (shape, dev) in zip(PARAM_NAMES, ctx.shapes)}
+        mlp_weight_grads(pk, ctx.acts, dys, ctx.encf, ctx.n, grads)
+        ctx.acts = None
+        return (None, None, None, None, None, None) + tuple(grads[n] for n in PARAM_NAMES)
+
+
+def query_nerf(model, t_vals, rays, viewf, S):
+    """One level of the NeRF MLP on the bf16 path: fenceposts in, raw density / colour out."""
+    cfg = model.config
+    n = t_vals.shape[0]
+    encf = encode_frag(t_vals, rays.origins, rays.directions, rays.radii, model.ray_shape, cfg.min_deg, cfg.max_deg)
+    p = dict(model.named_parameters())
+    params = [p[k] for k in PARAM_NAMES]
+    return _MlpNerf.apply(model, encf, viewf, n * S, S, n, *params)

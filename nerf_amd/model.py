@@ -162,11 +162,16 @@ class MipNeRF(_RenderModule):
         _xavier_init(self)
         self._packed = None
 
-    # -- one level of the MLP on [M, D] encodings ------------------------------------------
-    def _query(self, enc, view_feat, S):
+    # -- one level of the MLP ----------------------------------------------------------------
+    def _query(self, t_vals, rays, view_feat, S):
+        cfg = self.config
         if self._precision() == 'bf16':
             from . import mlp_bf16
-            return mlp_bf16.query_nerf(self, enc, view_feat, S)
+            return mlp_bf16.query_nerf(self, t_vals, rays, view_feat, S)
+        n = t_vals.shape[0]
+        with torch.no_grad():
+            mean, cov = ops.cast_rays(t_vals, rays.origins, rays.directions, rays.radii, self.ray_shape)
+            enc = ops.ipe_encode(mean, cov, cfg.min_deg, cfg.max_deg).reshape(n * S, -1)
         view_rows = view_feat[:, None, :].expand(-1, S, -1).reshape(-1, view_feat.shape[-1])   # model.py:127-128
         return mlp.mlp_forward_fp32(self._param_dict(), enc, view_rows, sar=False)
 
@@ -178,7 +183,11 @@ class MipNeRF(_RenderModule):
         levels = self._level_samples()
         o, d = rays.origins, rays.directions
         n = o.shape[0]
-        view_feat = ops.pe_encode(rays.viewdirs, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg, append_input=True)
+        if self._precision() == 'bf16':
+            from . import mlp_bf16
+            view_feat = mlp_bf16.view_frag(rays.viewdirs, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg)
+        else:
+            view_feat = ops.pe_encode(rays.viewdirs, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg, append_input=True)
         comp_rgbs, distances, accs = [], [], []
         t_vals = weights = rgb = density = None
         for l, S in enumerate(levels):
@@ -194,9 +203,7 @@ class MipNeRF(_RenderModule):
                         ur = (u_rand[l] if u_rand is not None else
                               torch.empty(n, S + 1, device=o.device).uniform_(0, 1 / (S + 1) - float(torch.finfo(torch.float32).eps)))
                     t_vals = ops.resample(t_vals, weights, S + 1, self.resample_padding, ur, blur=True)
-                mean, cov = ops.cast_rays(t_vals, o, d, rays.radii, self.ray_shape)
-                enc = ops.ipe_encode(mean, cov, cfg.min_deg, cfg.max_deg).reshape(n * S, -1)
-            raw_density, raw_rgb = self._query(enc, view_feat, S)
+            raw_density, raw_rgb = self._query(t_vals, rays, view_feat, S)
             raw_density = raw_density.reshape(n, S, 1)
             raw_rgb = raw_rgb.reshape(n, S, 3)
             if self.randomized and self.density_noise:
