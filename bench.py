@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""Benchmark of the render hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload ("step"): one full mip-NeRF training step on a batch of synthetic rays already resident in
+HBM -- coarse + fine render at 64+128 samples per ray (stratified sampling, cast + integrated positional
+encoding, 8x256 MLP with the bf16 MFMA chain, hierarchical resampling, alpha compositing), the masked-MSE
+loss over both levels, the hand-written backward of compositing and MLP, the gradient all-reduce across
+ranks (RCCL, N > 1), fused AdamW and the weight repack.  65,536 rays per step per GPU (weak scaling:
+the global batch grows with N), L=10/4 positional-encoding degrees, hidden 256, colour-layer width 128.
+
+Prints ONE JSON line on rank 0: whole-job rays/s, plus a roofline object for the dominant kernel family
+(HIP-event timing on the launching stream inside the timed region) and a CPU baseline (the numpy/torch
+oracle timed on a bounded ray sample on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 matrix peak
+HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak
+
+
+def make_cfg(precision='bf16'):
+    return SimpleNamespace(use_viewdirs=True, randomized=True, ray_shape='cone', white_bkgd=False, num_levels=2,
+                           num_samples=128, level_samples=[64, 128], min_deg=0, max_deg=10, viewdirs_min_deg=0,
+                           viewdirs_max_deg=4, density_noise=0.0, rgb_padding=0.001, resample_padding=0.01,
+                           density_bias=-1.0, hidden=256, coarse_weight_decay=0.1, lr_init=1e-3, lr_final=5e-5,
+                           max_steps=100000, lr_delay_steps=2500, lr_delay_mult=0.1, weight_decay=1e-5,
+                           mlp_precision=precision)
+
+
+def cpu_baseline(budget_rays=192, threads=None):
+    """The CPU oracle (fp32 restatement of the reference path) on a bounded sample of the same workload:
+    fwd + loss + bwd at 64+128 samples per ray, all host cores torch gives us."""
+    from oracle import nerf_oracle as O
+    if threads:
+        torch.set_num_threads(threads)
+    cfg = make_cfg('fp32')
+    p = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=0).items()}
+    g = torch.Generator().manual_seed(0)
+    n = budget_rays
+    o = 0.1 * torch.randn(n, 3, generator=g) + torch.tensor([0., 0., 4.])
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    rays = O.Rays(o, d, d.clone(), torch.full((n, 1), 0.005), torch.ones(n, 1), torch.full((n, 1), 2.),
+                  torch.full((n, 1), 6.))
+    tgt = torch.rand(n, 3, generator=g)
+    eps = float(torch.finfo(torch.float32).eps)
+
+    def step():
+        t_rand = torch.rand(n, 65, generator=g)
+        u_rand = {1: torch.empty(n, 129).uniform_(0, 1 / 129 - eps, generator=g)}
+        out = O.nerf_render(p, rays, cfg, [64, 128], t_rand, u_rand)
+        loss, _ = O.nerf_loss(out['comp_rgb_stack'], tgt, rays.lossmult, cfg.coarse_weight_decay)
+        loss.backward()
+        for v in p.values():
+            v.grad = None
+    step()
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or time.perf_counter() - t0 < 10.0:
+        step()
+        reps += 1
+        if time.perf_counter() - t0 > 30.0:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    return dict(value=n / dt, unit='rays/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{n} rays x (64+128) samples, fwd+loss+bwd (no optimizer), {reps} reps, fp32 torch-CPU oracle')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--rays', type=int, default=65536, help='rays per step per GPU')
+    ap.add_argument('--chunk', type=int, default=16384, help='rays per forward/backward chunk')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (the render path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from nerf_amd import profiling
+    from nerf_amd.model import MipNeRF
+    from nerf_amd.train import nerf_train_step, synthetic_rays
+
+    torch.manual_seed(0)
+    cfg = make_cfg(args.precision)
+    model = MipNeRF(cfg).to(dev).train()
+    if world > 1:                                    # identical replicas
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=cfg.lr_init, weight_decay=cfg.weight_decay, fused=True)
+    rays, pixels = synthetic_rays(args.rays, dev, seed=1234 + rank)
+    mask_sum = rays.lossmult.sum() * world
+
+    def step():
+        return nerf_train_step(model, rays, pixels, opt, chunk=args.chunk, world_size=world, global_mask_sum=mask_sum)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    profiling.enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = profiling.summary()
+    profiling.enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = args.rays * world * args.steps / dt
+        out = {
+            'metric': 'rays/sec fwd+bwd (64+128 samples/ray)', 'value': value, 'unit': 'rays/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+            'config': {'workload': 'C3: full NeRF train step (fwd+bwd+AdamW), coarse 64 + fine 128 samples/ray, '
+                                   '8x256 MLP (colour width 128), L=10/4 posenc',
+                       'rays_per_step_per_gpu': args.rays, 'global_rays_per_step': args.rays * world,
+                       'chunk_rays': args.chunk, 'parallelism': f'ray-sharded dp{world}, flat-bucket grad all-reduce',
+                       'loss': float(loss)},
+        }
+        if prof:
+            fam = {k: v['ms'] / args.steps for k, v in prof.items()}
+            out['kernel_ms_per_step'] = {k: round(v, 3) for k, v in fam.items()}
+            dom = max(fam, key=fam.get)
+            r = prof[dom]
+            if dom == 'mlp_wgrad':           # HBM-bound: algorithmic operand bytes / time
+                achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
+                out['roofline'] = {'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                                   'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                                   'calls_per_step': r['calls'] / args.steps}
+            else:                             # MFMA-bound: algorithmic FLOPs / time
+                achieved = r['flops'] / (r['ms'] * 1e-3) / 1e12
+                out['roofline'] = {'kernel': dom, 'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS,
+                                   'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'traffic': None,
+                                   'calls_per_step': r['calls'] / args.steps}
+            mlp_flops = sum(prof[k]['flops'] for k in prof if k.startswith('mlp_'))
+            mlp_ms = sum(prof[k]['ms'] for k in prof if k.startswith('mlp_'))
+            if mlp_ms > 0:
+                out['mlp_mfma_util'] = mlp_flops / (mlp_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -8,7 +8,7 @@ from ctypes import POINTER, c_float, c_int, c_int64, c_void_p
 
 import torch
 
-from . import _lib
+from . import _lib, profiling
 from ._lib import MlpDims, check, f32c, lib, ptr, stream
 
 _P = c_void_p
@@ -91,6 +91,16 @@ class Packed:
             c[o + 8] = 1.0 / H
             c[o + 9] = 1e-5
         self.consts = c
+        # algorithmic work per sample (true layer sizes): forward MACs, input-gradient MACs (no gradient
+        # w.r.t. the encodings), weight-gradient MACs; bytes = bf16 operands the weight-gradient pass must read
+        heads = 1 + (5 if self.sar else 3)
+        macs_fwd = D * H + 3 * H * H + (H + D) * H + 3 * H * H + H + H * H + (H + V) * W + (heads - 1) * W
+        macs_dx = macs_fwd - D * H - D * H - V * W
+        self.fwd_flops = 2.0 * macs_fwd
+        self.bwd_dx_flops = 2.0 * macs_dx
+        self.wgrad_flops = 2.0 * macs_fwd
+        HP, WP = 32 * self.HT, 32 * self.WT
+        self.wgrad_bytes = 2.0 * (9 * HP + WP + 64) + 2.0 * (16 * self.DKS * 2 + 8 * HP + HP + HP + 16 * self.VKS + WP)
 
 
 def packed_for(model, need_bwd=True):
@@ -139,9 +149,10 @@ def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False):
         widths = [32 * pk.HT] * 9 + [32 * pk.WT, 16 * pk.VKS]
         acts = [torch.empty(nblk * w * 128, dtype=torch.uint8, device=dev) for w in widths]
         arr = (c_void_p * 11)(*[a.data_ptr() for a in acts])
-    check(lib().nerf_mlp_fwd(ctypes.byref(pk.dims), _raw(pk.wfwd), ptr(pk.consts), _raw(enc), _raw(view), n_samples,
-                             ray_div, n_rays, arr, ptr(raw_density), ptr(raw_rgb), ptr(raw_angle), ptr(ln_stats),
-                             stream()))
+    with profiling.timed('mlp_fwd', flops=pk.fwd_flops * n_samples):
+        check(lib().nerf_mlp_fwd(ctypes.byref(pk.dims), _raw(pk.wfwd), ptr(pk.consts), _raw(enc), _raw(view),
+                                 n_samples, ray_div, n_rays, arr, ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
+                                 ptr(ln_stats), stream()))
     return raw_density, raw_rgb, raw_angle, acts, ln_stats
 
 
@@ -153,8 +164,10 @@ def mlp_backward(pk, acts, n_samples, g_density, g_rgb, raw_rgb):
     dys = [torch.empty(nblk * w * 128, dtype=torch.uint8, device=dev) for w in widths]
     a_arr = (c_void_p * 11)(*[a.data_ptr() for a in acts])
     d_arr = (c_void_p * 12)(*[d.data_ptr() for d in dys])
-    check(lib().nerf_mlp_bwd(ctypes.byref(pk.dims), _raw(pk.wbwd), n_samples, ptr(f32c(g_density).reshape(-1)),
-                             ptr(f32c(g_rgb).reshape(-1, 3)), None, ptr(raw_rgb), None, None, a_arr, d_arr, stream()))
+    g_density, g_rgb = f32c(g_density).reshape(-1), f32c(g_rgb).reshape(-1, 3)
+    with profiling.timed('mlp_bwd_dx', flops=pk.bwd_dx_flops * n_samples):
+        check(lib().nerf_mlp_bwd(ctypes.byref(pk.dims), _raw(pk.wbwd), n_samples, ptr(g_density), ptr(g_rgb), None,
+                                 ptr(raw_rgb), None, None, a_arr, d_arr, stream()))
     return dys
 
 
@@ -170,6 +183,11 @@ def mlp_weight_grads(pk, acts, dys, encf, n_samples, grads):
     DP, VP = 16 * pk.DKS, 16 * pk.VKS
     g = lambda n: (grads[n + '.weight'], grads[n + '.bias'])
     M = n_samples
+    with profiling.timed('mlp_wgrad', flops=pk.wgrad_flops * M, bytes_=pk.wgrad_bytes * M):
+        _all_wgrads(pk, acts, dys, encf, M, g, H, W, D, V, HP, WP, DP, VP)
+
+
+def _all_wgrads(pk, acts, dys, encf, M, g, H, W, D, V, HP, WP, DP, VP):
     # density_net0
     w, b = g('density_net0.0'); _wgrad(dys[0], HP, encf, DP, M, w, 0, H, D, b)
     for l, i in ((1, 2), (2, 4), (3, 6)):
