@@ -83,7 +83,7 @@ def main():
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--rays', type=int, default=65536, help='rays per step per GPU')
-    ap.add_argument('--chunk', type=int, default=16384, help='rays per forward/backward chunk')
+    ap.add_argument('--chunk', type=int, default=65536, help='rays per forward/backward chunk')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()

@@ -201,29 +201,33 @@ int nerf_view_frag(const float* dirs, int64_t n_rays, int min_deg, int max_deg, 
 /* Forward chain for n_samples rows: raw_density[M], raw_rgb[M,3] (after the sigmoid),
  * raw_angle[M,2] (SAR).  Row m takes the view features of ray m / ray_div (NeRF, ray_div = samples
  * per ray) or m % ray_div (SAR, ray_div = rays per chunk -- the row order upstream produces,
- * model.py:351-354).  acts: NULL for inference, else 11 device pointers (X0..X9 activations and
- * the view operand) that receive the bf16 fragments the backward pass reads; each sized
- * nblk * features * 128 bytes.                        reference: model.py:117-132, 343-359 */
+ * model.py:351-354).  acts: NULL for inference, else 22 device pointers that receive what the
+ * backward pass reads: [0..9] the activations X0..X9 as transposed bf16 fragments (nblk * features
+ * * 128 bytes each, nblk = 4 * ceil(M / 256)), [10..19] their ReLU sign words (nblk * 2 *
+ * ceil(features / 64) * 256 bytes; [18] unused, may be NULL), [20] / [21] the position encoding and
+ * view features as transposed fragments.             reference: model.py:117-132, 343-359 */
 int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* consts, const void* enc_frag,
                  const void* view_frag, int64_t n_samples, int ray_div, int64_t n_rays, void* const* acts,
                  float* raw_density, float* raw_rgb, float* raw_angle, float* ln_stats, void* stream);
 
 /* Backward chain of the fused MLP: from dL/d raw_density [M], dL/d raw_rgb [M,3] (w.r.t. the
  * post-sigmoid output; raw_rgb is that saved output) through every layer, writing dL/d(layer
- * pre-activation) as bf16 fragments: dys[0..9] for the ten streamed layers, dys[10] / dys[11] the
- * 32-row head tiles (colour heads / density head) the weight-gradient kernel consumes.  acts are
- * the buffers nerf_mlp_fwd saved.  NeRF heads only (SAR trains on the fp32 path).
+ * pre-activation) as transposed bf16 fragments (feature on the lane, 16 samples per k-step:
+ * [block of 32 samples][2][features/32][64 lanes][8]): dys[0..9] for the ten streamed layers,
+ * dys[10] / dys[11] the 32-row head tiles (colour heads / density head).  acts are the 22 buffers
+ * nerf_mlp_fwd saved (only the ReLU sign words acts[10..19] are read).  NeRF heads only (SAR trains
+ * on the fp32 path).
  *                              reference: autograd of model.py:117-132 (aten::mm, threshold_backward) */
 int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, int64_t n_samples, const float* g_density,
                  const float* g_rgb, const float* g_angle, const float* raw_rgb, const float* raw_angle,
                  const float* ln_stats, void* const* acts, void* const* dys, void* stream);
 
-/* Weight / bias gradient of one linear layer from fragments: G[n, col0 + k] += sum_m dY[m,n] X[m,k]
+/* Weight / bias gradient of one linear layer from transposed fragments: G[n, col0 + k] += sum_m dY[m,n] X[m,k]
  * (n < n_true, k < k_true; G is fp32 [n_true, ld]) and gb[n] += sum_m dY[m,n] (gb nullable).
  * n_feat / k_feat: padded feature counts of the two fragment buffers (multiples of 32, <= 256).
  * Accumulates with fp32 atomics: zero G / gb first for a fresh gradient.
  *                              reference: autograd of nn.Linear (aten::mm of dY^T and X, aten::sum) */
-int nerf_mlp_wgrad(const void* dy_frag, int n_feat, const void* x_frag, int k_feat, int64_t n_samples,
+int nerf_mlp_wgrad(const void* dy_tfrag, int n_feat, const void* x_tfrag, int k_feat, int64_t n_samples,
                    float* G, int ld, int col0, int n_true, int k_true, float* gb, int grid_hint, void* stream);
 
 #ifdef __cplusplus

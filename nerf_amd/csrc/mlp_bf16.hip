@@ -16,10 +16,17 @@
 // same permutation is baked into the packed weights and into every activation / gradient buffer:
 //   frag buffer of F features:  [block of 64 samples][F/16 k-steps][2 column tiles][64 lanes][8] bf16.
 //
+// Transposed fragments ("T-frag").  The weight gradient dW = dY^T X reduces over samples, so it wants the
+// feature on the lane and samples in registers.  A producer turns a finished pair of frag pieces into that
+// form with two more MFMAs against a constant permutation operand (exact: one 1.0 per column), and stores
+//   T-frag buffer of F features:  [block of 32 samples][2 k-steps of 16 samples][F/32 tiles][64 lanes][8] bf16,
+// lane l = 32*hh + n holding feature n of the tile, element j being sample 16*s + 8*(j>>2) + 4*hh + (j&3).
+// The weight-gradient kernel then streams T-frags HBM -> LDS -> MFMA operands with no transposition at all.
+// ReLU decisions travel to the backward chain as one bit per unit (a 32-bit word per lane per two tiles).
+//
 // Kernels: weight packing (forward and transposed streams), fused cast+IPE encoder and view-feature
 // encoder emitting frags, the forward chain, the backward chain (dX through all layers, emitting dY
-// frags), and the weight-gradient GEMM dW = dY^T X that transposes frags through LDS with
-// ds_read_b64_tr_b16.  bf16 inputs, fp32 accumulation; biases, heads and all epilogue math in fp32.
+// T-frags) and the streaming weight-gradient GEMM.  bf16 inputs, fp32 accumulation and epilogues.
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -43,6 +50,51 @@ __device__ __forceinline__ bf16x8 relu_bf16(bf16x8 x) {
     s16x8 v = __builtin_bit_cast(s16x8, x);
     v = __builtin_elementwise_max(v, (s16x8)(0));
     return __builtin_bit_cast(bf16x8, v);
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+// Sign bits of the 8 bf16 of piece s (0/1) of a tile: dword q of the piece lands on bits 4s+q (low half)
+// and 16+4s+q (high half) -- a tile's 16 units fill bits 0..7 and 16..23 of a word.
+__device__ __forceinline__ unsigned piece_sign_bits(bf16x8 o, int s) {
+    const u32x4 d = __builtin_bit_cast(u32x4, o);
+    unsigned w = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w |= ((d[q] >> 15) & 0x00010001u) << (4 * s + q);
+    return w;
+}
+// Zero the units whose keep-bit is clear (keep = inverted sign word of the saved pre-activation).
+__device__ __forceinline__ bf16x8 piece_apply_keep(bf16x8 g, unsigned keep, int s) {
+    u32x4 m;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m[q] = (keep >> (4 * s + q)) & 0x00010001u;
+    const u16x8 r = __builtin_bit_cast(u16x8, g) * __builtin_bit_cast(u16x8, m);
+    return __builtin_bit_cast(bf16x8, r);
+}
+// Constant B operand P_s (s = 0, 1): column n of a 32-column tile picks feature n out of k-step s.
+__device__ __forceinline__ void make_perm(bf16x8 (&P)[2], int lane) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            P[s][j] = (__bf16)(((lane & 31) == 16 * s + frag_feat(j, lane >> 5)) ? 1.0f : 0.0f);
+}
+// Transpose one 32-feature tile (frag pieces p0, p1: sample on the lane) into T-frag form and store it.
+__device__ __forceinline__ void emit_tfrag(bf16x8* dst, int64_t b32, int NT, int nt, int lane, bf16x8 p0, bf16x8 p1,
+                                           const bf16x8 (&P)[2]) {
+    f32x16 t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = 0.f;
+    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p0, P[0], t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, P[1], t, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)t[8 * s + j];
+        dst[((b32 * 2 + s) * NT + nt) * 64 + lane] = o;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -82,8 +134,10 @@ struct MlpFwdArgs {
     int64_t nblk;              // blocks of 64 samples
     int ray_div;               // NeRF: samples per ray S (ray = m / S);  SAR: rays per chunk R (ray = m % R)
     int n_rays;
-    bf16x8* act[10];           // saved activations X0..X9 (NULL pointers: inference, nothing saved)
-    bf16x8* act_view;          // saved view operand [nblk][VKS][2][64]
+    bf16x8* tx[10];            // saved activations X0..X9 as T-frags (training only)
+    unsigned* mask[10];        // ReLU sign words of X0..X7, X9: [b32][ceil(tiles/2)][64] (index 8 unused)
+    bf16x8* t_enc;             // position encoding as T-frags, ceil(DKS/2) tiles
+    bf16x8* t_view;            // view features as T-frags, ceil(VKS/2) tiles
     float* raw_density;        // [M]
     float* raw_rgb;            // [M,3]  (post sigmoid)
     float* raw_angle;          // [M,2]  (SAR, post sigmoid)
@@ -144,10 +198,12 @@ enum { EPI_PLAIN = 0, EPI_TRUNK = 1, EPI_HEAD = 2 };
 //   EPI_HEAD : a single 32-row tile whose first rows are network outputs; returned in `head` as fp32.
 template <class N, bool SAVE, int NT, int KS_M, int KS_E, int NEXT_KS, bool RELU, int EPI, int KM, int KE, int KO>
 __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[KM], const bf16x8 (&xe)[KE],
-                                          bf16x8 (&out)[KO], const float* bias, int h, bf16x8* save, int64_t blk,
-                                          int ct, float (&head)[4], float (&ln)[2]) {
+                                          bf16x8 (&out)[KO], const float* bias, int h, bf16x8* tsave,
+                                          unsigned* msave, int64_t b32, const bf16x8 (&P)[2], float (&head)[4],
+                                          float (&ln)[2]) {
     constexpr int KS = KS_M + KS_E;
     const int lane = pipe.lane;
+    unsigned signs = 0;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         if (nt + 1 < NT) pipe.template prefetch<KS>(pipe.cur ^ 1);
@@ -165,6 +221,7 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
             const bf16x8 b = ks < KS_M ? xm[ks < KS_M ? ks : 0] : xe[ks >= KS_M ? ks - KS_M : 0];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
+        constexpr bool kMask = SAVE && RELU;
         if (EPI == EPI_HEAD) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) head[q] = acc[q];          // rows 4h .. 4h+3 of the tile
@@ -182,14 +239,21 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
                 bf16x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (__bf16)acc[8 * s + j];
+                if (kMask) signs |= piece_sign_bits(o, s) << (8 * (nt & 1));
                 if (RELU) o = relu_bf16(o);
                 out[2 * nt + s] = o;
-                if (SAVE) save[((blk * (2 * NT) + 2 * nt + s) * 2 + ct) * 64 + lane] = o;
+            }
+            if (SAVE) emit_tfrag(tsave, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
+            if (kMask && ((nt & 1) || nt + 1 == NT)) {
+                msave[(b32 * ((NT + 1) / 2) + (nt >> 1)) * 64 + lane] = signs;
+                signs = 0;
             }
         }
-        // next stage must have landed; the 2 activation stores just issued (the youngest vector-memory
-        // operations of this wave) may stay in flight
-        pipe.template arrive<(SAVE && EPI != EPI_HEAD) ? 2 : 0>();
+        // next stage must have landed; the stores just issued (2 T-frag pieces, plus the sign word on every
+        // second tile -- the youngest vector-memory operations of this wave) may stay in flight
+        constexpr int kStores = (SAVE && EPI != EPI_HEAD) ? 2 : 0;
+        if (kMask && ((nt & 1) || nt + 1 == NT)) pipe.template arrive<kStores + 1>();
+        else pipe.template arrive<kStores>();
     }
 }
 
@@ -209,6 +273,9 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
 
     for (int i = tid; i < N::C_TOTAL; i += 512) cst[i] = a.consts[i];
 
+    const int64_t b32 = blk * 2 + ct;
+    bf16x8 P[2];
+    make_perm(P, lane);
     bf16x8 enc[N::DKS], view[N::VKS];
 #pragma unroll
     for (int ks = 0; ks < N::DKS; ++ks) enc[ks] = a.enc[((blk * N::DKS + ks) * 2 + ct) * 64 + lane];
@@ -217,10 +284,18 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
         const int64_t mm = m < a.M ? m : a.M - 1;
         const int64_t ray = N::SAR ? (mm % a.ray_div) : (mm / a.ray_div);
 #pragma unroll
-        for (int ks = 0; ks < N::VKS; ++ks) {
-            view[ks] = a.view[(ray * N::VKS + ks) * 2 + h];
-            if (SAVE) a.act_view[((blk * N::VKS + ks) * 2 + ct) * 64 + lane] = view[ks];
-        }
+        for (int ks = 0; ks < N::VKS; ++ks) view[ks] = a.view[(ray * N::VKS + ks) * 2 + h];
+    }
+    if (SAVE) {     // the layer inputs that are not activations, in T-frag form for the weight gradients
+        bf16x8 zero;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zero[j] = (__bf16)0.f;
+#pragma unroll
+        for (int i = 0; i < (N::DKS + 1) / 2; ++i)
+            emit_tfrag(a.t_enc, b32, (N::DKS + 1) / 2, i, lane, enc[2 * i], 2 * i + 1 < N::DKS ? enc[2 * i + 1 < N::DKS ? 2 * i + 1 : 0] : zero, P);
+#pragma unroll
+        for (int i = 0; i < (N::VKS + 1) / 2; ++i)
+            emit_tfrag(a.t_view, b32, (N::VKS + 1) / 2, i, lane, view[2 * i], 2 * i + 1 < N::VKS ? view[2 * i + 1 < N::VKS ? 2 * i + 1 : 0] : zero, P);
     }
     __syncthreads();
 
@@ -240,21 +315,21 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     constexpr int HKS = N::HKS, HT = N::HT;
     const float* bias = cst + N::C_BIAS;
     // density_net0: enc -> X0 -> X1 -> X2 -> X3
-    fwd_layer<N, SAVE, HT, 0, N::DKS, HKS, true, EPI_PLAIN>(pipe, none, enc, xa, bias + 0 * N::HP, h, a.act[0], blk, ct, hd_density, ln);
-    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 1 * N::HP, h, a.act[1], blk, ct, hd_density, ln);
-    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 2 * N::HP, h, a.act[2], blk, ct, hd_density, ln);
-    fwd_layer<N, SAVE, HT, HKS, 0, HKS + N::DKS, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 3 * N::HP, h, a.act[3], blk, ct, hd_density, ln);
+    fwd_layer<N, SAVE, HT, 0, N::DKS, HKS, true, EPI_PLAIN>(pipe, none, enc, xa, bias + 0 * N::HP, h, a.tx[0], a.mask[0], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 1 * N::HP, h, a.tx[1], a.mask[1], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 2 * N::HP, h, a.tx[2], a.mask[2], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, HT, HKS, 0, HKS + N::DKS, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 3 * N::HP, h, a.tx[3], a.mask[3], b32, P, hd_density, ln);
     // density_net1: [X3 | enc] -> X4 -> ... -> X7 (trunk output)
-    fwd_layer<N, SAVE, HT, HKS, N::DKS, HKS, true, EPI_PLAIN>(pipe, xb, enc, xa, bias + 4 * N::HP, h, a.act[4], blk, ct, hd_density, ln);
-    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 5 * N::HP, h, a.act[5], blk, ct, hd_density, ln);
-    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 6 * N::HP, h, a.act[6], blk, ct, hd_density, ln);
-    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_TRUNK>(pipe, xa, none, xb, bias + 7 * N::HP, h, a.act[7], blk, ct, hd_density, ln);
+    fwd_layer<N, SAVE, HT, HKS, N::DKS, HKS, true, EPI_PLAIN>(pipe, xb, enc, xa, bias + 4 * N::HP, h, a.tx[4], a.mask[4], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 5 * N::HP, h, a.tx[5], a.mask[5], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 6 * N::HP, h, a.tx[6], a.mask[6], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_TRUNK>(pipe, xa, none, xb, bias + 7 * N::HP, h, a.tx[7], a.mask[7], b32, P, hd_density, ln);
     // final_density as one more output tile on X7 (row 0), then rgb_net0 (no activation): X7 -> X8
-    fwd_layer<N, SAVE, 1, HKS, 0, HKS, false, EPI_HEAD>(pipe, xb, none, xw, cst + N::C_BIASD, h, nullptr, blk, ct, hd_density, ln);
-    fwd_layer<N, SAVE, HT, HKS, 0, HKS + N::VKS, false, EPI_PLAIN>(pipe, xb, none, xa, bias + 8 * N::HP, h, a.act[8], blk, ct, hd_colour, ln);
+    fwd_layer<N, SAVE, 1, HKS, 0, HKS, false, EPI_HEAD>(pipe, xb, none, xw, cst + N::C_BIASD, h, nullptr, nullptr, b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, HT, HKS, 0, HKS + N::VKS, false, EPI_PLAIN>(pipe, xb, none, xa, bias + 8 * N::HP, h, a.tx[8], nullptr, b32, P, hd_colour, ln);
     // rgb_net1: [X8 | view] -> X9 ; final_rgb (+ final_angle) as one output tile on X9 (rows 0..4)
-    fwd_layer<N, SAVE, N::WT, HKS, N::VKS, N::WKS, true, EPI_PLAIN>(pipe, xa, view, xw, cst + N::C_BIAS9, h, a.act[9], blk, ct, hd_colour, ln);
-    fwd_layer<N, SAVE, 1, N::WKS, 0, 0, false, EPI_HEAD>(pipe, xw, none, xa, cst + N::C_BIASH, h, nullptr, blk, ct, hd_colour, ln);
+    fwd_layer<N, SAVE, N::WT, HKS, N::VKS, N::WKS, true, EPI_PLAIN>(pipe, xa, view, xw, cst + N::C_BIAS9, h, a.tx[9], a.mask[9], b32, P, hd_colour, ln);
+    fwd_layer<N, SAVE, 1, N::WKS, 0, 0, false, EPI_HEAD>(pipe, xw, none, xa, cst + N::C_BIASH, h, nullptr, nullptr, b32, P, hd_colour, ln);
 
     // outputs.  Lane half 0 holds rows 0..3 of a head tile, half 1 rows 4..7.
     const float* sc = cst + N::C_SC;
@@ -289,8 +364,8 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // Backward chain: dY_i = (W_{i+1}^T dY_{i+1}) * [X_i > 0], all layers in one launch, same register
 // chaining as the forward pass (the fp32 accumulator tile of one layer's input gradient is the B
-// operand of the next product).  Reads the saved bf16 activations only for the ReLU masks, writes
-// every dY as bf16 frags for the weight-gradient kernel.
+// operand of the next product).  Reads only the ReLU sign words; writes every dY as T-frags for the
+// weight-gradient kernel.
 struct MlpBwdArgs {
     const bf16x8* wbwd;        // packed transposed weight stream
     int64_t M, nblk;
@@ -300,35 +375,26 @@ struct MlpBwdArgs {
     const float* raw_rgb;      // [M,3] saved sigmoid outputs
     const float* raw_angle;    // [M,2]
     const float* ln_stats;     // [M,2] (SAR)
-    const bf16x8* act[10];     // X0..X9
-    bf16x8* dy[10];            // dY0..dY9
-    bf16x8* dy_hd;             // [nblk][2][2][64] head tile of dL/d(pre-sigmoid colour/angle outputs), rows 0..4
-    bf16x8* dy_dens;           // [nblk][2][2][64] head tile of dL/d raw_density (row 0)
+    const unsigned* mask[10];  // ReLU sign words of X0..X9 (index 8 unused)
+    bf16x8* tdy[10];           // dY0..dY9 as T-frags
+    bf16x8* tdy_hd;            // 1-tile T-frag of dL/d(pre-sigmoid colour outputs), rows 0..4
+    bf16x8* tdy_dens;          // 1-tile T-frag of dL/d raw_density (row 0)
 };
 
-// mask = all-ones where the (non-negative) saved activation is non-zero
-__device__ __forceinline__ bf16x8 relu_mask_apply(bf16x8 g, bf16x8 x) {
-    const s16x8 xs = __builtin_bit_cast(s16x8, x);
-    const s16x8 m = ((s16x8)(0) - xs) >> 15;
-    return __builtin_bit_cast(bf16x8, (s16x8)(__builtin_bit_cast(s16x8, g) & m));
-}
-
 // One backward layer: NT output tiles (features of the layer INPUT), reduction over KS_M k-steps of
-// `gm` (the layer's dY) then KS_E of `ge`.  MASKED: multiply by [act > 0] with `act` the saved input.
+// `gm` (the layer's dY) then KS_E of `ge`.  MASKED: zero the units whose saved pre-activation was negative.
 template <class N, int NT, int KS_M, int KS_E, int NEXT_KS, bool MASKED, int KM, int KE, int KO>
 __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[KM], const bf16x8 (&ge)[KE],
-                                          bf16x8 (&out)[KO], const bf16x8* act, bf16x8* dy, int64_t blk, int ct) {
+                                          bf16x8 (&out)[KO], const unsigned* mask, bf16x8* tdy, int64_t b32,
+                                          const bf16x8 (&P)[2]) {
     constexpr int KS = KS_M + KS_E;
     const int lane = pipe.lane;
+    unsigned keep = 0;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         if (nt + 1 < NT) pipe.template prefetch<KS>(pipe.cur ^ 1);
         else pipe.template prefetch<NEXT_KS>(pipe.cur ^ 1);
-        bf16x8 xk[2];
-        if (MASKED) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) xk[s] = act[((blk * (2 * NT) + 2 * nt + s) * 2 + ct) * 64 + lane];
-        }
+        if (MASKED && (nt & 1) == 0) keep = ~mask[(b32 * ((NT + 1) / 2) + (nt >> 1)) * 64 + lane];
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -343,10 +409,10 @@ __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[K
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (__bf16)acc[8 * s + j];
-            if (MASKED) o = relu_mask_apply(o, xk[s]);
+            if (MASKED) o = piece_apply_keep(o, keep >> (8 * (nt & 1)), s);
             out[2 * nt + s] = o;
-            dy[((blk * (2 * NT) + 2 * nt + s) * 2 + ct) * 64 + lane] = o;
         }
+        emit_tfrag(tdy, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
         pipe.template arrive<2>();
     }
 }
@@ -361,8 +427,11 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
     const int c = lane & 31, h = lane >> 5;
     const int ct = wave & 1;
     const int64_t blk = (int64_t)blockIdx.x * 4 + (wave >> 1);
+    const int64_t b32 = blk * 2 + ct;
     const int64_t m = blk * 64 + ct * 32 + c;
     const bool ok = m < a.M;
+    bf16x8 P[2];
+    make_perm(P, lane);
 
     // gradient w.r.t. the pre-sigmoid head outputs and the raw density, as one-k-step B operands:
     // rows 0..3 of a head tile are elements 0..3 of lane half 0, row 4 is element 0 of lane half 1.
@@ -377,11 +446,8 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
         }
         dd[0] = (__bf16)a.g_density[m];
     }
-    // head tiles for the weight-gradient kernel (32 rows = two k-steps, the second all zero)
-    a.dy_hd[((blk * 2 + 0) * 2 + ct) * 64 + lane] = dz;
-    a.dy_hd[((blk * 2 + 1) * 2 + ct) * 64 + lane] = zero;
-    a.dy_dens[((blk * 2 + 0) * 2 + ct) * 64 + lane] = dd;
-    a.dy_dens[((blk * 2 + 1) * 2 + ct) * 64 + lane] = zero;
+    emit_tfrag(a.tdy_hd, b32, 1, 0, lane, dz, zero, P);
+    emit_tfrag(a.tdy_dens, b32, 1, 0, lane, dd, zero, P);
 
     WeightPipe pipe;
     pipe.src = (const char*)a.wbwd;
@@ -396,53 +462,54 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
     constexpr int HKS = N::HKS, HT = N::HT, WKS = N::WKS;
     bf16x8 ga[HKS], gb[HKS], gw[WKS], none[1], dzv[1] = {dz}, ddv[1] = {dd};
     // heads^T: dX9 = Wh^T dz, masked by X9 > 0 -> dY9
-    bwd_layer<N, N::WT, 1, 0, WKS, true>(pipe, dzv, none, gw, a.act[9], a.dy[9], blk, ct);
+    bwd_layer<N, N::WT, 1, 0, WKS, true>(pipe, dzv, none, gw, a.mask[9], a.tdy[9], b32, P);
     // rgb_net1^T (rows of X8 only): dY8 = W9[:, :H]^T dY9   (rgb_net0 has no activation)
-    bwd_layer<N, HT, WKS, 0, HKS + 1, false>(pipe, gw, none, ga, nullptr, a.dy[8], blk, ct);
+    bwd_layer<N, HT, WKS, 0, HKS + 1, false>(pipe, gw, none, ga, nullptr, a.tdy[8], b32, P);
     // [rgb_net0 ; density head]^T: dX7 = W8^T dY8 + wd^T dd, masked by X7 > 0 -> dY7
-    bwd_layer<N, HT, HKS, 1, HKS, true>(pipe, ga, ddv, gb, a.act[7], a.dy[7], blk, ct);
-    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, gb, none, ga, a.act[6], a.dy[6], blk, ct);
-    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, ga, none, gb, a.act[5], a.dy[5], blk, ct);
-    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, gb, none, ga, a.act[4], a.dy[4], blk, ct);
+    bwd_layer<N, HT, HKS, 1, HKS, true>(pipe, ga, ddv, gb, a.mask[7], a.tdy[7], b32, P);
+    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, gb, none, ga, a.mask[6], a.tdy[6], b32, P);
+    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, ga, none, gb, a.mask[5], a.tdy[5], b32, P);
+    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, gb, none, ga, a.mask[4], a.tdy[4], b32, P);
     // density_net1.0^T (rows of X3 only; the encoding needs no gradient)
-    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, ga, none, gb, a.act[3], a.dy[3], blk, ct);
-    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, gb, none, ga, a.act[2], a.dy[2], blk, ct);
-    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, ga, none, gb, a.act[1], a.dy[1], blk, ct);
-    bwd_layer<N, HT, HKS, 0, 0, true>(pipe, gb, none, ga, a.act[0], a.dy[0], blk, ct);
+    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, ga, none, gb, a.mask[3], a.tdy[3], b32, P);
+    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, gb, none, ga, a.mask[2], a.tdy[2], b32, P);
+    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, ga, none, gb, a.mask[1], a.tdy[1], b32, P);
+    bwd_layer<N, HT, HKS, 0, 0, true>(pipe, gb, none, ga, a.mask[0], a.tdy[0], b32, P);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Weight gradient: G[n][col0 + k] += sum_m dY[m][n] X[m][k], gb[n] += sum_m dY[m][n].
-// Both operands arrive as frags (sample on the lane, features in registers) but the reduction runs
-// over samples, so each 64-sample block is laid out in LDS as a [sample][feature] image (8-byte
-// units XOR-swizzled so that both the fill and the transposed reads spread over the banks) and read
-// back with ds_read_b64_tr_b16: lane = feature, registers = 4 consecutive samples.
-// HBM-bound (each operand byte is used for 2*256 FLOP): one workgroup of 4 waves per CU, persistent
-// over blocks, the next block's 16 loads per thread in flight while the current one is multiplied.
+// Weight gradient: G[n][col0 + k] += sum_m dY[m][n] X[m][k], gb[n] += sum_m dY[m][n], both operands
+// given as T-frags, i.e. already in MFMA operand order for a reduction over samples.  Pure streaming
+// GEMM, HBM-bound (every operand byte feeds 2*256 FLOP): a workgroup of 4 waves owns the whole
+// [NT x KT]-tile output in registers and takes every grid-th 16-sample k-step; each k-step's
+// NT + KT pieces go HBM -> LDS by global_load_lds into a ring of `depth` slots, depth-2 k-steps in
+// flight behind a counted vmcnt, one barrier per k-step.
 struct WgradArgs {
-    const bf16x8* dy;          // [nblk][2*NT][2][64]
-    const bf16x8* x;           // [nblk][2*KT][2][64]
-    int64_t nblk;
+    const bf16x8* a;           // dY T-frags  [nq][NT][64]
+    const bf16x8* b;           // X  T-frags  [nq][KT][64]
+    int64_t nq;                // 16-sample k-steps
     int NT, KT, WN, WK;
+    int depth;                 // ring slots: depth - 2 k-steps stay in flight
     float* G;                  // fp32 [n_true][ld]
     int ld, col0, n_true, k_true;
     float* gb;                 // fp32 [n_true] or NULL
 };
 
-__device__ __forceinline__ unsigned img_off(int row, int cb, unsigned row_bytes) {
-    // cb: byte column (multiple of 8).  64-byte chunks swizzled by row&3 (when the row has >= 4 chunks),
-    // 8-byte units inside a chunk by (row>>2)&7.
-    const unsigned nchunk = row_bytes >> 6;
-    unsigned chunk = (unsigned)cb >> 6;
-    if ((nchunk & (nchunk - 1)) == 0) chunk ^= (row & 3) & (nchunk - 1);
-    const unsigned unit = (((unsigned)cb >> 3) & 7) ^ ((row >> 2) & 7);
-    return row * row_bytes + (chunk << 6) + (unit << 3);
-}
+constexpr int kWgradLds = 156 * 1024;      // ring + 4 KiB landing zone for padding loads
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-// ds_read_b64_tr_b16 through the compiler's builtin, so its LDS wait is tracked like any other read
-__device__ __forceinline__ bf16x4 lds_tr_read(LDS_AS const char* p) {
-    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)p));
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in 0..63 (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define NERF_W1(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+#define NERF_W8(a, b, c, d, e, f, g, h) NERF_W1(a) NERF_W1(b) NERF_W1(c) NERF_W1(d) NERF_W1(e) NERF_W1(f) NERF_W1(g) NERF_W1(h)
+    switch (n) {
+        NERF_W8(0, 1, 2, 3, 4, 5, 6, 7) NERF_W8(8, 9, 10, 11, 12, 13, 14, 15)
+        NERF_W8(16, 17, 18, 19, 20, 21, 22, 23) NERF_W8(24, 25, 26, 27, 28, 29, 30, 31)
+        NERF_W8(32, 33, 34, 35, 36, 37, 38, 39) NERF_W8(40, 41, 42, 43, 44, 45, 46, 47)
+        NERF_W8(48, 49, 50, 51, 52, 53, 54, 55) NERF_W8(56, 57, 58, 59, 60, 61, 62, 63)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef NERF_W8
+#undef NERF_W1
 }
 
 template <int NTW, int KTW>
@@ -452,94 +519,86 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(WgradArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave / a.WK, wk = wave % a.WK;
-    const unsigned rb_y = a.NT * 64, rb_x = a.KT * 64;            // image row bytes (32 features * 2 B per tile)
-    LDS_AS char* img_y = (LDS_AS char*)smem;
-    LDS_AS char* img_x = img_y + 64 * rb_y;
-    const int pieces_y = a.NT * 4, pieces_x = a.KT * 4;           // 1 KiB pieces per block: (2*NT k-steps) x 2 column tiles
-    const int per_thread = (pieces_y + pieces_x + 3) / 4;         // pieces are dealt round-robin to the 4 waves
-    bf16x8 stage[16];
-
+    const int P = a.NT + a.KT;                         // pieces per k-step
+    const int G = (P + 3) >> 2;                        // loads per wave per k-step (1..4), same for every wave
+    const unsigned slot_bytes = P * 1024;
+    LDS_AS char* ring = (LDS_AS char*)smem;
+    const int depth = a.depth;
+    LDS_AS char* scratch = ring + depth * slot_bytes;  // landing zone of the padding loads
+    // k-steps are dealt round-robin: at any moment the workgroups together sweep one contiguous window of
+    // each operand (grid * NT KiB), which spreads over all HBM channels; contiguous per-workgroup ranges
+    // would put every workgroup on the same channel at the same time.
+    const int64_t q0 = blockIdx.x, qstride = gridDim.x;
+    const int64_t n = q0 < a.nq ? (a.nq - q0 + qstride - 1) / qstride : 0;
     f32x16 acc[NTW][KTW];
-    f32x16 accb[NTW];
+    float accb[NTW];                                   // bias gradient: this lane's feature, its half of the samples
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+        accb[i] = 0.f;
 #pragma unroll
         for (int j = 0; j < KTW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    const bool do_bias = a.gb != nullptr && wk == 0;
 
-    auto load_block = [&](int64_t b) {
+    // every wave issues exactly G loads per k-step, real pieces first, padding into the scratch KiB
+    int fill = 0, drain = 0;                           // ring positions of the next k-step to load / to consume
+    auto issue = [&](int64_t i) {
+        const int64_t q = q0 + i * qstride;
+        LDS_AS char* slot = ring + (unsigned)fill * slot_bytes;
+        fill = fill + 1 == depth ? 0 : fill + 1;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int p = i * 4 + wave;
-            if (i < per_thread && p < pieces_y + pieces_x)
-                stage[i] = p < pieces_y ? a.dy[(b * pieces_y + p) * 64 + lane] : a.x[(b * pieces_x + (p - pieces_y)) * 64 + lane];
-        }
-    };
-    auto store_block = [&]() {
-        const int c = lane & 31, h = lane >> 5;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int p = i * 4 + wave;
-            if (i < per_thread && p < pieces_y + pieces_x) {
-                const bool isy = p < pieces_y;
-                const int q = isy ? p : p - pieces_y;              // piece = (k-step ks, column tile ct)
-                const int ks = q >> 1, ct = q & 1;
-                const int row = ct * 32 + c;
-                const int cb = 32 * ks + 8 * h;
-                LDS_AS char* img = isy ? img_y : img_x;
-                const unsigned rb = isy ? rb_y : rb_x;
-                const bf16x4 lo = __builtin_shufflevector(stage[i], stage[i], 0, 1, 2, 3);
-                const bf16x4 hi = __builtin_shufflevector(stage[i], stage[i], 4, 5, 6, 7);
-                *(LDS_AS bf16x4*)(img + img_off(row, cb, rb)) = lo;
-                *(LDS_AS bf16x4*)(img + img_off(row, cb + 16, rb)) = hi;
+        for (int g = 0; g < 4; ++g) {
+            if (g < G) {
+                const int p = g * 4 + wave;
+                const char* src = (const char*)a.a;
+                LDS_AS char* dst = scratch + wave * 1024;
+                if (i < n && p < P) {
+                    src = p < a.NT ? (const char*)(a.a + (q * a.NT + p) * 64) : (const char*)(a.b + (q * a.KT + (p - a.NT)) * 64);
+                    dst = slot + p * 1024;
+                }
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + lane * 16), (LDS_AS void*)dst, 16, 0, 0);
             }
         }
     };
-    // operand (32 features starting at f0, 16 samples starting at s0): lane = feature, 8 consecutive samples
-    auto read_operand = [&](LDS_AS const char* img, unsigned rb, int f0, int s0) -> bf16x8 {
-        const int g = lane >> 4, i = lane & 15;
-        const int row = s0 + 8 * (g >> 1) + (i >> 2);
-        const int cb = f0 * 2 + 32 * (g & 1) + 8 * (i & 3);
-        const bf16x4 lo = lds_tr_read(img + img_off(row, cb, rb));
-        const bf16x4 hi = lds_tr_read(img + img_off(row + 4, cb, rb));
-        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    };
 
-    int64_t b = blockIdx.x;
-    if (b < a.nblk) load_block(b);
-    for (; b < a.nblk; b += gridDim.x) {
-        __syncthreads();                       // everyone finished reading the previous image
-        store_block();
-        __syncthreads();
-        if (b + gridDim.x < a.nblk) load_block(b + gridDim.x);
+    const int in_flight = (depth - 2) * G;
+    for (int i = 0; i < depth - 1; ++i) issue(i);
+    for (int64_t i = 0; i < n; ++i) {
+        wait_vmcnt(in_flight);
+        __builtin_amdgcn_s_barrier();
+        issue(i + depth - 1);
+        LDS_AS const char* slot = ring + (unsigned)drain * slot_bytes;
+        drain = drain + 1 == depth ? 0 : drain + 1;
+        bf16x8 A[NTW], B[KTW];
 #pragma unroll
-        for (int ms = 0; ms < 4; ++ms) {
-            bf16x8 A[NTW], B[KTW];
+        for (int ii = 0; ii < NTW; ++ii) {
+            const int nt = wn * NTW + ii;
+            A[ii] = *(LDS_AS const bf16x8*)(slot + (nt < a.NT ? nt : 0) * 1024 + lane * 16);
+        }
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) {
-                const int nt = wn * NTW + i;
-                A[i] = read_operand(img_y, rb_y, (nt < a.NT ? nt : 0) * 32, ms * 16);
-            }
+        for (int j = 0; j < KTW; ++j) {
+            const int kt = wk * KTW + j;
+            B[j] = *(LDS_AS const bf16x8*)(slot + (a.NT + (kt < a.KT ? kt : 0)) * 1024 + lane * 16);
+        }
 #pragma unroll
-            for (int j = 0; j < KTW; ++j) {
-                const int kt = wk * KTW + j;
-                B[j] = read_operand(img_x, rb_x, (kt < a.KT ? kt : 0) * 32, ms * 16);
-            }
+        for (int ii = 0; ii < NTW; ++ii)
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) {
+            for (int j = 0; j < KTW; ++j) acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ii], B[j], acc[ii][j], 0, 0, 0);
+        if (do_bias) {                                  // column sums of dY on the vector ALU, under the MFMAs
 #pragma unroll
-                for (int j = 0; j < KTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc[i][j], 0, 0, 0);
-                if (a.gb != nullptr && wk == 0) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], ones, accb[i], 0, 0, 0);
+            for (int ii = 0; ii < NTW; ++ii) {
+                const u32x4 d = __builtin_bit_cast(u32x4, A[ii]);
+                float t = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t += __uint_as_float(d[q] << 16) + __uint_as_float(d[q] & 0xffff0000u);
+                accb[ii] += t;
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS write may outlive the workgroup
+
     // flush: accumulator element r of lane l is dW[row n = tile*32 + acc_row(r, l>>5)][col k = tile*32 + (l&31)]
     const int h = lane >> 5, c = lane & 31;
 #pragma unroll
@@ -554,16 +613,13 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(WgradArgs a) {
             if (k >= a.k_true) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = nt * 32 + acc_row(r, h);
-                if (n < a.n_true) atomicAdd(&a.G[(int64_t)n * a.ld + a.col0 + k], acc[i][j][r]);
+                const int nn = nt * 32 + acc_row(r, h);
+                if (nn < a.n_true) atomicAdd(&a.G[(int64_t)nn * a.ld + a.col0 + k], acc[i][j][r]);
             }
         }
-        if (a.gb != nullptr && wk == 0 && c == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = nt * 32 + acc_row(r, h);
-                if (n < a.n_true) atomicAdd(&a.gb[n], accb[i][r]);
-            }
+        if (do_bias) {
+            const int nn = nt * 32 + c;
+            if (nn < a.n_true) atomicAdd(&a.gb[nn], accb[i]);
         }
     }
 }
@@ -782,7 +838,7 @@ static int launch_fwd_t(const MlpFwdArgs& a, hipStream_t st) {
 }
 template <class N>
 static int launch_fwd(const MlpFwdArgs& a, hipStream_t st) {
-    return a.act[0] != nullptr ? launch_fwd_t<N, true>(a, st) : launch_fwd_t<N, false>(a, st);
+    return a.tx[0] != nullptr ? launch_fwd_t<N, true>(a, st) : launch_fwd_t<N, false>(a, st);
 }
 
 extern "C" int nerf_mlp_sizes(const nerf_mlp_dims* dims, int64_t* wfwd_bytes, int64_t* wbwd_bytes,
@@ -881,7 +937,7 @@ extern "C" int nerf_view_frag(const float* dirs, int64_t n_rays, int min_deg, in
 
 extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* consts, const void* enc_frag,
                             const void* view_frag, int64_t n_samples, int ray_div, int64_t n_rays,
-                            void* const* acts /* 11 pointers (X0..X9, view) or NULL */, float* raw_density,
+                            void* const* acts /* 22 pointers or NULL */, float* raw_density,
                             float* raw_rgb, float* raw_angle, float* ln_stats, void* stream) {
     if (n_samples == 0) return NERF_OK;
     HostDims d;
@@ -897,8 +953,14 @@ extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const f
     a.nblk = ((n_samples + 255) / 256) * 4;      // blocks of 64 samples, whole workgroups
     a.ray_div = ray_div;
     a.n_rays = (int)n_rays;
-    for (int i = 0; i < 10; ++i) a.act[i] = acts ? (bf16x8*)acts[i] : nullptr;
-    a.act_view = acts ? (bf16x8*)acts[10] : nullptr;
+    // acts (training): 0..9 T-frags of X0..X9, 10..19 sign-word buffers, 20 enc T-frags, 21 view T-frags
+    for (int i = 0; i < 10; ++i) {
+        a.tx[i] = acts ? (bf16x8*)acts[i] : nullptr;
+        a.mask[i] = acts ? (unsigned*)acts[10 + i] : nullptr;
+    }
+    a.t_enc = acts ? (bf16x8*)acts[20] : nullptr;
+    a.t_view = acts ? (bf16x8*)acts[21] : nullptr;
+    if (acts) for (int i = 0; i < 22; ++i) NERF_REQUIRE(acts[i] != nullptr || i == 18);
     a.raw_density = raw_density;
     a.raw_rgb = raw_rgb;
     a.raw_angle = raw_angle;
@@ -927,8 +989,9 @@ static int launch_bwd(const MlpBwdArgs& a, hipStream_t st) {
 
 extern "C" int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, int64_t n_samples, const float* g_density,
                             const float* g_rgb, const float* g_angle, const float* raw_rgb, const float* raw_angle,
-                            const float* ln_stats, void* const* acts, void* const* dys /* 12: dY0..dY9, colour head tile,
-                            density head tile */, void* stream) {
+                            const float* ln_stats, void* const* acts /* as nerf_mlp_fwd */,
+                            void* const* dys /* 12 T-frag buffers: dY0..dY9, colour head tile, density head tile */,
+                            void* stream) {
     if (n_samples == 0) return NERF_OK;
     HostDims d;
     NERF_REQUIRE(make_dims(dims, &d) && wbwd && g_density && g_rgb && raw_rgb && acts && dys && n_samples > 0);
@@ -940,13 +1003,13 @@ extern "C" int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, int64_t
     a.g_density = g_density; a.g_rgb = g_rgb; a.g_angle = g_angle;
     a.raw_rgb = raw_rgb; a.raw_angle = raw_angle; a.ln_stats = ln_stats;
     for (int i = 0; i < 10; ++i) {
-        NERF_REQUIRE(acts[i] && dys[i]);
-        a.act[i] = (const bf16x8*)acts[i];
-        a.dy[i] = (bf16x8*)dys[i];
+        NERF_REQUIRE((acts[10 + i] || i == 8) && dys[i]);
+        a.mask[i] = (const unsigned*)acts[10 + i];
+        a.tdy[i] = (bf16x8*)dys[i];
     }
     NERF_REQUIRE(dys[10] && dys[11]);
-    a.dy_hd = (bf16x8*)dys[10];
-    a.dy_dens = (bf16x8*)dys[11];
+    a.tdy_hd = (bf16x8*)dys[10];
+    a.tdy_dens = (bf16x8*)dys[11];
 #define X(ht_, wt_, dks_, vks_, sar_)                                                            \
     if (!sar_ && d.HT == ht_ && d.WT == wt_ && d.DKS == dks_ && d.VKS == vks_ && d.sar == 0)      \
         return launch_bwd<Net<ht_, wt_, dks_, vks_, false>>(a, nerf_stream(stream));
@@ -960,7 +1023,7 @@ static int launch_wgrad(const WgradArgs& a, unsigned grid, size_t lds, hipStream
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)mlp_wgrad_kernel<NTW, KTW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                128 * 1024) != hipSuccess)
+                                kWgradLds) != hipSuccess)
             return NERF_ERR_LAUNCH;
         attr_set = true;
     }
@@ -968,40 +1031,46 @@ static int launch_wgrad(const WgradArgs& a, unsigned grid, size_t lds, hipStream
     return nerf_launch_status();
 }
 
-// G[n_true, ld] (+= at column col0, k_true columns) and gb[n_true] (nullable) accumulate
-// dY^T X over n_samples rows; dy_frag has n_feat features (multiple of 32, <= 256), x_frag k_feat
-// features (multiple of 16, <= 256; a trailing half tile is zero-extended).
-extern "C" int nerf_mlp_wgrad(const void* dy_frag, int n_feat, const void* x_frag, int k_feat, int64_t n_samples,
+// G[n_true, ld] (+= at column col0, k_true columns) and gb[n_true] (nullable) accumulate dY^T X over
+// n_samples rows; dy_tfrag has n_feat features, x_tfrag k_feat features (multiples of 32, <= 256).
+extern "C" int nerf_mlp_wgrad(const void* dy_tfrag, int n_feat, const void* x_tfrag, int k_feat, int64_t n_samples,
                               float* G, int ld, int col0, int n_true, int k_true, float* gb, int grid_hint,
                               void* stream) {
     if (n_samples == 0) return NERF_OK;
-    NERF_REQUIRE(dy_frag && x_frag && G && n_samples > 0 && n_feat > 0 && k_feat > 0 && n_feat % 32 == 0 &&
+    NERF_REQUIRE(dy_tfrag && x_tfrag && G && n_samples > 0 && n_feat > 0 && k_feat > 0 && n_feat % 32 == 0 &&
                  k_feat % 32 == 0 && n_feat <= 256 && k_feat <= 256 && n_true <= n_feat && k_true <= k_feat);
     WgradArgs a;
-    a.dy = (const bf16x8*)dy_frag;
-    a.x = (const bf16x8*)x_frag;
-    a.nblk = ((n_samples + 255) / 256) * 4;
+    a.a = (const bf16x8*)dy_tfrag;
+    a.b = (const bf16x8*)x_tfrag;
+    a.nq = ((n_samples + 255) / 256) * 16;            // 16-sample k-steps, whole 256-sample workgroup tiles
     a.NT = n_feat / 32;
     a.KT = k_feat / 32;
-    a.WN = a.NT >= 4 ? 4 : (a.NT >= 2 ? 2 : 1);
-    a.WK = 4 / a.WN;
+    // split the output tiles over the 4 waves (WN x WK) so that the per-wave block fits an instantiated
+    // template with the fewest accumulator tiles
+    static const int kSplit[3][2] = {{2, 2}, {4, 1}, {1, 4}};
+    static const int kTmpl[6][2] = {{1, 1}, {1, 2}, {1, 4}, {2, 2}, {2, 4}, {4, 4}};
+    int best = 1 << 30, tn = 0, tk = 0;
+    for (const auto& sp : kSplit) {
+        const int ntw = (a.NT + sp[0] - 1) / sp[0], ktw = (a.KT + sp[1] - 1) / sp[1];
+        for (const auto& t : kTmpl)
+            if (t[0] >= ntw && t[1] >= ktw && t[0] * t[1] < best) {
+                best = t[0] * t[1]; tn = t[0]; tk = t[1]; a.WN = sp[0]; a.WK = sp[1];
+            }
+    }
+    if (tn == 0) return NERF_ERR_SIZE;
     a.G = G; a.ld = ld; a.col0 = col0; a.n_true = n_true; a.k_true = k_true; a.gb = gb;
-    const int ntw = (a.NT + a.WN - 1) / a.WN, ktw = (a.KT + a.WK - 1) / a.WK;
     unsigned grid = grid_hint > 0 ? (unsigned)grid_hint : 256u;
-    if ((int64_t)grid > a.nblk) grid = (unsigned)a.nblk;
-    const size_t lds = (size_t)64 * 64 * (a.NT + a.KT);
+    if ((int64_t)grid > a.nq) grid = (unsigned)a.nq;
+    // as deep a ring as the LDS and the 6-bit vmcnt allow
+    const int pieces = a.NT + a.KT, loads = (pieces + 3) / 4;
+    a.depth = (kWgradLds / 1024 - 4) / pieces;
+    if ((a.depth - 2) * loads > 63) a.depth = 63 / loads + 2;
+    const size_t lds = (size_t)(a.depth * pieces + 4) * 1024;
     hipStream_t st = nerf_stream(stream);
-    if (ntw <= 1) {
-        if (ktw <= 1) return launch_wgrad<1, 1>(a, grid, lds, st);
-        if (ktw <= 2) return launch_wgrad<1, 2>(a, grid, lds, st);
-        if (ktw <= 4) return launch_wgrad<1, 4>(a, grid, lds, st);
-        return launch_wgrad<1, 8>(a, grid, lds, st);
-    }
-    if (ntw <= 2) {
-        if (ktw <= 1) return launch_wgrad<2, 1>(a, grid, lds, st);
-        if (ktw <= 2) return launch_wgrad<2, 2>(a, grid, lds, st);
-        if (ktw <= 4) return launch_wgrad<2, 4>(a, grid, lds, st);
-        return launch_wgrad<2, 8>(a, grid, lds, st);
-    }
-    return NERF_ERR_SIZE;
+    if (tn == 1 && tk == 1) return launch_wgrad<1, 1>(a, grid, lds, st);
+    if (tn == 1 && tk == 2) return launch_wgrad<1, 2>(a, grid, lds, st);
+    if (tn == 1 && tk == 4) return launch_wgrad<1, 4>(a, grid, lds, st);
+    if (tn == 2 && tk == 2) return launch_wgrad<2, 2>(a, grid, lds, st);
+    if (tn == 2 && tk == 4) return launch_wgrad<2, 4>(a, grid, lds, st);
+    return launch_wgrad<4, 4>(a, grid, lds, st);
 }

@@ -99,8 +99,27 @@ class Packed:
         self.fwd_flops = 2.0 * macs_fwd
         self.bwd_dx_flops = 2.0 * macs_dx
         self.wgrad_flops = 2.0 * macs_fwd
-        HP, WP = 32 * self.HT, 32 * self.WT
-        self.wgrad_bytes = 2.0 * (9 * HP + WP + 64) + 2.0 * (16 * self.DKS * 2 + 8 * HP + HP + HP + 16 * self.VKS + WP)
+        self.DT, self.VT = (self.DKS + 1) // 2, (self.VKS + 1) // 2
+        # bf16 operand bytes per sample that the weight-gradient launches read (see _wgrad_plan)
+        self.wgrad_bytes = 2.0 * sum(nf + kf for _, nf, _, kf, *_ in _wgrad_plan(self))
+
+
+def _wgrad_plan(pk):
+    """The weight-gradient launches of one backward pass:
+    (dY index, dY features, X source, X features, parameter, column offset, true rows, true cols, with bias).
+    X sources: ('x', i) saved activation i, 'enc', 'view'.  dY 10 / 11 are the colour / density head tiles."""
+    H, W, D, V = pk.H, pk.W, pk.D, pk.V
+    HP, WP, DP, VP = 32 * pk.HT, 32 * pk.WT, 32 * pk.DT, 32 * pk.VT
+    plan = [(0, HP, 'enc', DP, 'density_net0.0', 0, H, D, True)]
+    plan += [(l, HP, ('x', l - 1), HP, 'density_net0.%d' % i, 0, H, H, True) for l, i in ((1, 2), (2, 4), (3, 6))]
+    plan += [(4, HP, ('x', 3), HP, 'density_net1.0', 0, H, H, True), (4, HP, 'enc', DP, 'density_net1.0', H, H, D, False)]
+    plan += [(l, HP, ('x', l - 1), HP, 'density_net1.%d' % i, 0, H, H, True) for l, i in ((5, 2), (6, 4), (7, 6))]
+    plan += [(11, 32, ('x', 7), HP, 'final_density.0', 0, 1, H, True),
+             (8, HP, ('x', 7), HP, 'rgb_net0.0', 0, H, H, True),
+             (9, WP, ('x', 8), HP, 'rgb_net1.0', 0, W, H, True),
+             (9, WP, 'view', VP, 'rgb_net1.0', H, W, V, False),
+             (10, 32, ('x', 9), WP, 'final_rgb.0', 0, 3, W, True)]
+    return plan
 
 
 def packed_for(model, need_bwd=True):
@@ -146,9 +165,14 @@ def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False):
     ln_stats = torch.empty(n_samples, 2, device=dev) if (pk.sar and save) else None
     acts = arr = None
     if save:
-        widths = [32 * pk.HT] * 9 + [32 * pk.WT, 16 * pk.VKS]
-        acts = [torch.empty(nblk * w * 128, dtype=torch.uint8, device=dev) for w in widths]
-        arr = (c_void_p * 11)(*[a.data_ptr() for a in acts])
+        # 0..9 X0..X9 as T-frags, 10..19 their ReLU sign words (X8 has no activation), 20 enc, 21 view T-frags
+        tiles = [pk.HT] * 9 + [pk.WT]
+        acts = [torch.empty(nblk * t * 4096, dtype=torch.uint8, device=dev) for t in tiles]
+        acts += [torch.empty(nblk * 2 * ((t + 1) // 2) * 256, dtype=torch.uint8, device=dev) if i != 8 else None
+                 for i, t in enumerate(tiles)]
+        acts += [torch.empty(nblk * pk.DT * 4096, dtype=torch.uint8, device=dev),
+                 torch.empty(nblk * pk.VT * 4096, dtype=torch.uint8, device=dev)]
+        arr = (c_void_p * 22)(*[a.data_ptr() if a is not None else None for a in acts])
     with profiling.timed('mlp_fwd', flops=pk.fwd_flops * n_samples):
         check(lib().nerf_mlp_fwd(ctypes.byref(pk.dims), _raw(pk.wfwd), ptr(pk.consts), _raw(enc), _raw(view),
                                  n_samples, ray_div, n_rays, arr, ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
@@ -157,12 +181,12 @@ def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False):
 
 
 def mlp_backward(pk, acts, n_samples, g_density, g_rgb, raw_rgb):
-    """Backward chain -> list of 12 dY fragment buffers (dY0..dY9, colour head tile, density head tile)."""
+    """Backward chain -> list of 12 dY T-frag buffers (dY0..dY9, colour head tile, density head tile)."""
     dev = g_density.device
     nblk = n_blocks(n_samples)
-    widths = [32 * pk.HT] * 9 + [32 * pk.WT, 32, 32]
-    dys = [torch.empty(nblk * w * 128, dtype=torch.uint8, device=dev) for w in widths]
-    a_arr = (c_void_p * 11)(*[a.data_ptr() for a in acts])
+    tiles = [pk.HT] * 9 + [pk.WT, 1, 1]
+    dys = [torch.empty(nblk * t * 4096, dtype=torch.uint8, device=dev) for t in tiles]
+    a_arr = (c_void_p * 22)(*[a.data_ptr() if a is not None else None for a in acts])
     d_arr = (c_void_p * 12)(*[d.data_ptr() for d in dys])
     g_density, g_rgb = f32c(g_density).reshape(-1), f32c(g_rgb).reshape(-1, 3)
     with profiling.timed('mlp_bwd_dx', flops=pk.bwd_dx_flops * n_samples):
@@ -176,34 +200,14 @@ def _wgrad(dy, n_feat, x, k_feat, n_samples, G, col0, n_true, k_true, gb):
                                ptr(gb), 0, stream()))
 
 
-def mlp_weight_grads(pk, acts, dys, encf, n_samples, grads):
+def mlp_weight_grads(pk, acts, dys, n_samples, grads):
     """Accumulate all weight / bias gradients into `grads` (name -> zero-initialised or running fp32 tensor)."""
-    H, W, D, V = pk.H, pk.W, pk.D, pk.V
-    HP, WP = 32 * pk.HT, 32 * pk.WT
-    DP, VP = 16 * pk.DKS, 16 * pk.VKS
-    g = lambda n: (grads[n + '.weight'], grads[n + '.bias'])
     M = n_samples
     with profiling.timed('mlp_wgrad', flops=pk.wgrad_flops * M, bytes_=pk.wgrad_bytes * M):
-        _all_wgrads(pk, acts, dys, encf, M, g, H, W, D, V, HP, WP, DP, VP)
-
-
-def _all_wgrads(pk, acts, dys, encf, M, g, H, W, D, V, HP, WP, DP, VP):
-    # density_net0
-    w, b = g('density_net0.0'); _wgrad(dys[0], HP, encf, DP, M, w, 0, H, D, b)
-    for l, i in ((1, 2), (2, 4), (3, 6)):
-        w, b = g('density_net0.%d' % i); _wgrad(dys[l], HP, acts[l - 1], HP, M, w, 0, H, H, b)
-    # density_net1 (first layer: [X3 | enc])
-    w, b = g('density_net1.0')
-    _wgrad(dys[4], HP, acts[3], HP, M, w, 0, H, H, b)
-    _wgrad(dys[4], HP, encf, DP, M, w, H, H, D, None)
-    for l, i in ((5, 2), (6, 4), (7, 6)):
-        w, b = g('density_net1.%d' % i); _wgrad(dys[l], HP, acts[l - 1], HP, M, w, 0, H, H, b)
-    w, b = g('final_density.0'); _wgrad(dys[11], 32, acts[7], HP, M, w, 0, 1, H, b)
-    w, b = g('rgb_net0.0'); _wgrad(dys[8], HP, acts[7], HP, M, w, 0, H, H, b)
-    w, b = g('rgb_net1.0')
-    _wgrad(dys[9], WP, acts[8], HP, M, w, 0, W, H, b)
-    _wgrad(dys[9], WP, acts[10], VP, M, w, H, W, V, None)
-    w, b = g('final_rgb.0'); _wgrad(dys[10], 32, acts[9], WP, M, w, 0, 3, W, b)
+        for di, nf, xs, kf, name, col0, n_true, k_true, with_bias in _wgrad_plan(pk):
+            x = acts[20] if xs == 'enc' else acts[21] if xs == 'view' else acts[xs[1]]
+            _wgrad(dys[di], nf, x, kf, M, grads[name + '.weight'], col0, n_true, k_true,
+                   grads[name + '.bias'] if with_bias else None)
 
 
 PARAM_NAMES = [n + s for n in STREAMED + ['final_density.0', 'final_rgb.0'] for s in ('.weight', '.bias')]
@@ -217,7 +221,7 @@ class _MlpNerf(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[6:])
         pk = packed_for(model, need_bwd=need_grad)
         d, rgb, _, acts, _ = mlp_forward(pk, encf, viewf, n_samples, ray_div, n_rays, save=need_grad)
-        ctx.pk, ctx.acts, ctx.encf, ctx.n = pk, acts, encf, n_samples
+        ctx.pk, ctx.acts, ctx.n = pk, acts, n_samples
         ctx.shapes = [(p.shape, p.device) for p in params]
         ctx.save_for_backward(rgb)
         return d.reshape(-1, 1), rgb
@@ -228,7 +232,7 @@ class _MlpNerf(torch.autograd.Function):
         pk = ctx.pk
         dys = mlp_backward(pk, ctx.acts, ctx.n, g_density, g_rgb, rgb)
         grads = {n: torch.zeros(shape, device=dev, dtype=torch.float32) for n, (shape, dev) in zip(PARAM_NAMES, ctx.shapes)}
-        mlp_weight_grads(pk, ctx.acts, dys, ctx.encf, ctx.n, grads)
+        mlp_weight_grads(pk, ctx.acts, dys, ctx.n, grads)
         ctx.acts = None
         return (None, None, None, None, None, None) + tuple(grads[n] for n in PARAM_NAMES)
 

@@ -26,10 +26,8 @@ def test_header_symbols_exported():
 def test_bindings_cover_header():
     from nerf_amd import _lib
     import nerf_amd.ops  # noqa: F401  (registers every binding)
-    try:
-        import nerf_amd.mlp  # noqa: F401
-    except ImportError:
-        pass
+    import nerf_amd.mlp  # noqa: F401
+    import nerf_amd.mlp_bf16  # noqa: F401
     bound = set(_lib.exported_symbols())
     assert set(_declared()) <= bound, sorted(set(_declared()) - bound)
     L = _lib.lib()

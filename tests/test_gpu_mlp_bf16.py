@@ -76,6 +76,19 @@ def frag_to_dense(buf, F, M):
     return out[:M]
 
 
+def tfrag_to_dense(buf, F, M):
+    """Unpack a transposed-fragment buffer [block of 32][2][F/32][64][8] to a dense fp32 [M, F] matrix."""
+    NT = F // 32
+    nb = buf.numel() // (2 * NT * 1024)
+    x = buf.view(torch.bfloat16).reshape(nb, 2, NT, 2, 32, 8).float().cpu()
+    out = torch.zeros(nb, 32, NT, 32)
+    for s in range(2):
+        for hh in range(2):
+            for j in range(8):
+                out[:, 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)] = x[:, s, :, hh, :, j]
+    return out.reshape(nb * 32, F)[:M]
+
+
 def fro(a, b):
     return float((a - b).norm() / b.norm())
 
@@ -110,10 +123,11 @@ def test_mlp_backward_chain_exact_structure(tag, kw, S, n):
     dys = mlp_bf16.mlp_backward(pk, acts, M, ga.cuda().reshape(-1), gb.cuda(), rgbk)
     H, W, D, V = cfg.hidden, cfg.num_samples, pk.D, pk.V
     HP, WP = pk.HT * 32, pk.WT * 32
-    X = [frag_to_dense(acts[i], HP if i < 9 else WP, M) for i in range(10)]
-    DY = [frag_to_dense(dys[i], HP if i < 9 else WP, M) for i in range(10)]
-    E = frag_to_dense(encf, pk.DKS * 16, M)[:, :D]
-    VW = frag_to_dense(acts[10], pk.VKS * 16, M)[:, :V]
+    X = [tfrag_to_dense(acts[i], HP if i < 9 else WP, M) for i in range(10)]
+    DY = [tfrag_to_dense(dys[i], HP if i < 9 else WP, M) for i in range(10)]
+    E = tfrag_to_dense(acts[20], pk.DT * 32, M)[:, :D]
+    assert torch.equal(E, frag_to_dense(encf, pk.DKS * 16, M)[:, :D])         # the transposition is exact
+    VW = tfrag_to_dense(acts[21], pk.VT * 32, M)[:, :V]
     bf = lambda w: w.to(torch.bfloat16).float()
     Wt = [bf(p[nm + '.weight']) for nm in mlp_bf16.STREAMED]
     s = rgbk.cpu()
@@ -129,7 +143,7 @@ def test_mlp_backward_chain_exact_structure(tag, kw, S, n):
         assert fro(DY[i][:, :H], r) < 5e-3, i
     # weight gradients from the kernel's own fragments
     grads = {nm: torch.zeros_like(v, device='cuda') for nm, v in p.items()}
-    mlp_bf16.mlp_weight_grads(pk, acts, dys, encf, M, grads)
+    mlp_bf16.mlp_weight_grads(pk, acts, dys, M, grads)
     ins = [E, X[0], X[1], X[2], torch.cat([X[3][:, :H], E], 1), X[4], X[5], X[6], X[7], torch.cat([X[8][:, :H], VW], 1)]
     for i, nm in enumerate(mlp_bf16.STREAMED):
         dy = DY[i][:, :p[nm + '.weight'].shape[0]]
