@@ -19,8 +19,8 @@
 // Transposed fragments ("T-frag").  The weight gradient dW = dY^T X reduces over samples, so it wants the
 // feature on the lane and samples in registers.  A producer turns a finished pair of frag pieces into that
 // form with two more MFMAs against a constant permutation operand (exact: one 1.0 per column), and stores
-//   T-frag buffer of F features:  [block of 32 samples][2 k-steps of 16 samples][F/32 tiles][64 lanes][8] bf16,
-// lane l = 32*hh + n holding feature n of the tile, element j being sample 16*s + 8*(j>>2) + 4*hh + (j&3).
+//   T-frag buffer of F features:  [k-step of 16 samples][F/32 tiles][64 lanes][8] bf16,
+// lane l = 32*hh + n holding feature n of the tile, element j being sample 8*(j>>2) + 4*hh + (j&3) of the k-step.
 // The weight-gradient kernel then streams T-frags HBM -> LDS -> MFMA operands with no transposition at all.
 // ReLU decisions travel to the backward chain as one bit per unit (a 32-bit word per lane per two tiles).
 //
@@ -72,6 +72,10 @@ __device__ __forceinline__ bf16x8 piece_apply_keep(bf16x8 g, unsigned keep, int 
     const u16x8 r = __builtin_bit_cast(u16x8, g) * __builtin_bit_cast(u16x8, m);
     return __builtin_bit_cast(bf16x8, r);
 }
+// Index of the 1 KiB piece holding 16-sample k-step q (= 2 * block-of-32 + half), tile nt, in a T-frag buffer
+// of NT tiles.  (Tile-major runs of 2..16 k-steps were measured: the chain kernels' stores do not care, the
+// weight-gradient kernel prefers its NT KiB per k-step contiguous.)
+__device__ __forceinline__ int64_t tfrag_piece(int64_t q, int NT, int nt) { return q * NT + nt; }
 // Constant B operand P_s (s = 0, 1): column n of a 32-column tile picks feature n out of k-step s.
 __device__ __forceinline__ void make_perm(bf16x8 (&P)[2], int lane) {
 #pragma unroll
@@ -93,9 +97,17 @@ __device__ __forceinline__ void emit_tfrag(bf16x8* dst, int64_t b32, int NT, int
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (__bf16)t[8 * s + j];
-        dst[((b32 * 2 + s) * NT + nt) * 64 + lane] = o;
+        __builtin_nontemporal_store(o, &dst[tfrag_piece(b32 * 2 + s, NT, nt) * 64 + lane]);
     }
 }
+
+// Slots of the weight ring in LDS.  A stage's weights are fetched kRing-1 stages ahead; because a wave's
+// vector-memory operations retire in order, that is also how many stages an activation store may take to
+// complete before it holds up a weight fetch queued behind it.
+#ifndef NERF_RING
+#define NERF_RING 3
+#endif
+constexpr int kRing = NERF_RING;
 
 // ------------------------------------------------------------------------------------------------
 // Network geometry (compile time).  HT/WT: 32-row tiles of the hidden width / colour-layer width;
@@ -114,9 +126,9 @@ struct Net {
     static constexpr int C_SC = C_BIASH + 32;            // scalars: [6] sum(w*gamma) [7] sum(w*beta) [8] 1/H [9] eps
     static constexpr int C_TOTAL = C_SC + 16;
     static constexpr int SLOT_KS = HKS + (DKS > VKS ? DKS : VKS);
-    static constexpr int FWD_LDS = C_TOTAL * 4 + 2 * SLOT_KS * 1024;
+    static constexpr int FWD_LDS = C_TOTAL * 4 + (kRing * SLOT_KS + 1) * 1024;   // + 1 KiB landing zone
     static constexpr int BWD_SLOT_KS = (HKS + 1) > WKS ? (HKS + 1) : WKS;
-    static constexpr int BWD_LDS = C_TOTAL * 4 + 2 * BWD_SLOT_KS * 1024;
+    static constexpr int BWD_LDS = (kRing * BWD_SLOT_KS + 1) * 1024;
     // pieces (1 KiB) in the packed streams
     // forward: L0, L1-3, L4, L5-7, density head tile, L8, L9, rgb/angle head tile
     static constexpr int FWD_PIECES = HT * DKS + 3 * HT * HKS + HT * (HKS + DKS) + 3 * HT * HKS + HKS + HT * HKS +
@@ -150,38 +162,128 @@ struct MlpFwdArgs {
 // 4*blockIdx + (w >> 1) and loads pieces w, w+8, ... of every stage.
 constexpr int kWaves = 8;
 
+// Per-stage facts the pipeline's counted waits need.  A stage = one output tile: fetch weights kRing-1 stages
+// ahead, run the tile's MFMAs, and -- under those MFMAs -- finish the PREVIOUS tile (convert, activation,
+// transposition, stores).  The last tile of a layer is finished after the layer's last stage, i.e. ahead of
+// the next stage's fetch.  Program order of a wave's vector-memory operations within stage k:
+//   pre stores | fetch of stage k+kRing-1 (stage_loads) | extra loads | stores.
+struct StageDesc { int ks, pre, xloads, stores; };
+
+// Forward stages: L0, L1-3, L4, L5-7 (HT tiles each), density head (1), L8 (HT), L9 (WT), colour heads (1).
+template <class N, bool SAVE>
+constexpr StageDesc fwd_stage(int i) {
+    constexpr int kL = 12;
+    const int tiles[kL] = {N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, 1, N::HT, N::WT, 1};
+    const int ks[kL] = {N::DKS, N::HKS, N::HKS, N::HKS, N::HKS + N::DKS, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS,
+                        N::HKS + N::VKS, N::WKS};
+    const int kind[kL] = {2, 2, 2, 2, 2, 2, 2, 2, 0, 1, 2, 0};     // 0 head (nothing saved), 1 saved, 2 saved + sign words
+    // stores that finishing tile t of layer l issues: 2 T-frag pieces, + the sign word after every second tile
+    auto tile_stores = [&](int l, int t) {
+        return (!SAVE || kind[l] == 0) ? 0 : 2 + ((kind[l] == 2 && ((t & 1) || t + 1 == tiles[l])) ? 1 : 0);
+    };
+    if (i < 0) return {0, 0, 0, 0};
+    for (int l = 0; l < kL; ++l) {
+        if (i < tiles[l])
+            return {ks[l], (i == 0 && l > 0) ? tile_stores(l - 1, tiles[l - 1] - 1) : 0, 0, i > 0 ? tile_stores(l, i - 1) : 0};
+        i -= tiles[l];
+    }
+    return {0, 0, 0, 0};
+}
+// Backward stages: heads^T (WT tiles, 1 k-step), L9^T (HT, WKS), L8^T + density row (HT, HKS+1), 7 x (HT, HKS).
+// Finishing a tile stores 2 T-frag pieces; the first stage of a layer also loads the next masked layer's sign words.
+template <class N>
+constexpr StageDesc bwd_stage(int i) {
+    constexpr int kL = 10;
+    const int tiles[kL] = {N::WT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT};
+    const int ks[kL] = {1, N::WKS, N::HKS + 1, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS};
+    const bool masked[kL + 1] = {true, false, true, true, true, true, true, true, true, true, false};
+    if (i < 0) return {0, 0, 0, 0};
+    for (int l = 0; l < kL; ++l) {
+        if (i < tiles[l])
+            return {ks[l], (i == 0 && l > 0) ? 2 : 0, (i == 0 && masked[l + 1]) ? (tiles[l + 1] + 1) / 2 : 0, i > 0 ? 2 : 0};
+        i -= tiles[l];
+    }
+    return {0, 0, 0, 0};
+}
+constexpr int stage_loads(int ks) { return (ks + 7) / 8; }       // fetches per wave (8 waves share a stage)
+
+// Vector-memory operations a wave has issued after the fetch of stage s+1 by the time stage s ends.
+template <class N, bool SAVE>
+constexpr int fwd_younger(int s) {
+    int y = fwd_stage<N, SAVE>(s + 2 - kRing).xloads + fwd_stage<N, SAVE>(s + 2 - kRing).stores;
+    for (int k = s + 3 - kRing; k <= s; ++k)
+        y += fwd_stage<N, SAVE>(k).pre + stage_loads(fwd_stage<N, SAVE>(k + kRing - 1).ks) + fwd_stage<N, SAVE>(k).xloads +
+             fwd_stage<N, SAVE>(k).stores;
+    return y;
+}
+template <class N>
+constexpr int bwd_younger(int s) {
+    int y = bwd_stage<N>(s + 2 - kRing).xloads + bwd_stage<N>(s + 2 - kRing).stores;
+    for (int k = s + 3 - kRing; k <= s; ++k)
+        y += bwd_stage<N>(k).pre + stage_loads(bwd_stage<N>(k + kRing - 1).ks) + bwd_stage<N>(k).xloads + bwd_stage<N>(k).stores;
+    return y;
+}
+
+// Compile-time loop: f(IC<B>{}), ..., f(IC<E-1>{}); the index is usable in template arguments.
+template <int I>
+struct IC { static constexpr int value = I; };
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(IC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
 struct WeightPipe {
-    const char* src;           // next piece to prefetch (wave-uniform)
+    const char* src;           // next piece to fetch (wave-uniform)
+    const char* base;          // start of the stream: source of padding fetches
     unsigned slot_bytes;
-    LDS_AS char* ring;         // two slots
+    LDS_AS char* ring;         // kRing slots, then a 1 KiB landing zone for padding fetches
     int cur;                   // slot holding the stage being consumed
     int wave, lane;
 
+    // Fetch the next stage of the stream into `slot`.  Every wave issues stage_loads(KS) operations (waves
+    // without a piece fetch padding), so the counted waits hold for all of them.
     template <int KS>
-    __device__ __forceinline__ void prefetch(int slot) {
+    __device__ __forceinline__ void fetch(int slot) {
         if (KS == 0) return;
         LDS_AS char* dst = ring + slot * slot_bytes;
+        LDS_AS char* dump = ring + kRing * slot_bytes;
 #pragma unroll
-        for (int p = 0; p < (KS + kWaves - 1) / kWaves; ++p) {
+        for (int p = 0; p < stage_loads(KS); ++p) {
             const int piece = p * kWaves + wave;
-            if ((p + 1) * kWaves <= KS || piece < KS)
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + piece * 1024 + lane * 16),
-                                                 (LDS_AS void*)(dst + piece * 1024), 16, 0, 0);
+            const bool real = (p + 1) * kWaves <= KS || piece < KS;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)((real ? src + piece * 1024 : base) + lane * 16),
+                                             (LDS_AS void*)(real ? dst + piece * 1024 : dump), 16, 0, 0);
         }
         src += KS * 1024;
     }
-    // Every piece this wave prefetched has landed, except that the YOUNGER most recent vector-memory
-    // operations (activation stores issued after the prefetch) may stay in flight; then the workgroup
-    // barrier makes all waves' pieces visible.
+    template <int KS>
+    __device__ __forceinline__ void prefetch() { fetch<KS>((cur + kRing - 1) % kRing); }
+    // Start of the kernel: stages 0 .. kRing-2 into slots 0 .. kRing-2, wait for all of them.
+    template <int KS0, int KS1, int KS2, int KS3>
+    __device__ __forceinline__ void prime() {
+        static_assert(kRing >= 2 && kRing <= 5, "prime() fetches at most four stages");
+        cur = 0;
+        fetch<KS0>(0);
+        if (kRing > 2) fetch<KS1>(1);
+        if (kRing > 3) fetch<KS2>(2);
+        if (kRing > 4) fetch<KS3>(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // The next stage's pieces have landed (all but the YOUNGER most recent vector-memory operations of this
+    // wave are complete); the workgroup barrier then makes every wave's pieces visible.
     template <int YOUNGER>
     __device__ __forceinline__ void arrive() {
         // Pin the instruction schedule at the stage boundary: without it the scheduler drifts one stage's
         // register-only epilogue across several later stages and keeps all their accumulators alive.
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER < 63 ? YOUNGER : 63) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        cur ^= 1;
+        cur = (cur + 1) % kRing;
     }
     __device__ __forceinline__ bf16x8 piece(int ks) const {
         return *(const LDS_AS bf16x8*)(ring + cur * slot_bytes + ks * 1024 + lane * 16);
@@ -191,23 +293,56 @@ struct WeightPipe {
 enum { EPI_PLAIN = 0, EPI_TRUNK = 1, EPI_HEAD = 2 };
 
 // One layer: NT output tiles; inputs = KS_M k-steps from `xm` then KS_E k-steps from `xe`.
-// On entry the current pipe slot holds the layer's first stage.  NEXT_KS = piece count of the stage
-// that follows this layer's last one (0 at the end of the network).
+// On entry the current pipe slot holds the layer's first stage, which is stage STAGE0 of fwd_stage().
 //   EPI_PLAIN: activation -> bf16 B operand of the next layer (and saved for the backward pass);
 //   EPI_TRUNK: as PLAIN, plus (SAR) running sum / sum of squares of the fp32 outputs for the LayerNorm;
 //   EPI_HEAD : a single 32-row tile whose first rows are network outputs; returned in `head` as fp32.
-template <class N, bool SAVE, int NT, int KS_M, int KS_E, int NEXT_KS, bool RELU, int EPI, int KM, int KE, int KO>
+template <class N, bool SAVE, int STAGE0, int NT, int KS_M, int KS_E, bool RELU, int EPI, int KM, int KE, int KO>
 __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[KM], const bf16x8 (&xe)[KE],
                                           bf16x8 (&out)[KO], const float* bias, int h, bf16x8* tsave,
                                           unsigned* msave, int64_t b32, const bf16x8 (&P)[2], float (&head)[4],
                                           float (&ln)[2]) {
     constexpr int KS = KS_M + KS_E;
+    constexpr bool kMask = SAVE && RELU;
     const int lane = pipe.lane;
     unsigned signs = 0;
+#define NERF_FS(i) fwd_stage<N, SAVE>(i)
+    static_assert(NERF_FS(STAGE0).ks == KS && NERF_FS(STAGE0 + NT - 1).ks == KS, "stage table out of step");
+    // finish tile nt from its accumulator: activation, bf16 B operand of the next layer, saved copies
+    auto finish = [&](auto ntc, const f32x16& acc) __attribute__((always_inline)) {
+        constexpr int nt = decltype(ntc)::value;
+        if (EPI == EPI_HEAD) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        if (nt + 1 < NT) pipe.template prefetch<KS>(pipe.cur ^ 1);
-        else pipe.template prefetch<NEXT_KS>(pipe.cur ^ 1);
+            for (int q = 0; q < 4; ++q) head[q] = acc[q];          // rows 4h .. 4h+3 of the tile
+            return;
+        }
+        if (EPI == EPI_TRUNK && N::SAR) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = relu_f(acc[r]);
+                ln[0] += x;
+                ln[1] += x * x;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (__bf16)acc[8 * s + j];
+            if (kMask) signs |= piece_sign_bits(o, s) << (8 * (nt & 1));
+            if (RELU) o = relu_bf16(o);
+            out[2 * nt + s] = o;
+        }
+        if (SAVE) emit_tfrag(tsave, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
+        if (kMask && ((nt & 1) || nt + 1 == NT)) {
+            __builtin_nontemporal_store(signs, &msave[(b32 * ((NT + 1) / 2) + (nt >> 1)) * 64 + lane]);
+            signs = 0;
+        }
+    };
+    f32x16 prev;
+    static_for<0, NT>([&](auto ntc) __attribute__((always_inline)) {
+        constexpr int nt = decltype(ntc)::value;
+        pipe.template prefetch<NERF_FS(STAGE0 + nt + kRing - 1).ks>();
         f32x16 acc;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -221,40 +356,12 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
             const bf16x8 b = ks < KS_M ? xm[ks < KS_M ? ks : 0] : xe[ks >= KS_M ? ks - KS_M : 0];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
-        constexpr bool kMask = SAVE && RELU;
-        if (EPI == EPI_HEAD) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) head[q] = acc[q];          // rows 4h .. 4h+3 of the tile
-        } else {
-            if (EPI == EPI_TRUNK && N::SAR) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float x = relu_f(acc[r]);
-                    ln[0] += x;
-                    ln[1] += x * x;
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (__bf16)acc[8 * s + j];
-                if (kMask) signs |= piece_sign_bits(o, s) << (8 * (nt & 1));
-                if (RELU) o = relu_bf16(o);
-                out[2 * nt + s] = o;
-            }
-            if (SAVE) emit_tfrag(tsave, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
-            if (kMask && ((nt & 1) || nt + 1 == NT)) {
-                msave[(b32 * ((NT + 1) / 2) + (nt >> 1)) * 64 + lane] = signs;
-                signs = 0;
-            }
-        }
-        // next stage must have landed; the stores just issued (2 T-frag pieces, plus the sign word on every
-        // second tile -- the youngest vector-memory operations of this wave) may stay in flight
-        constexpr int kStores = (SAVE && EPI != EPI_HEAD) ? 2 : 0;
-        if (kMask && ((nt & 1) || nt + 1 == NT)) pipe.template arrive<kStores + 1>();
-        else pipe.template arrive<kStores>();
-    }
+        if constexpr (nt > 0) finish(IC<nt - 1>{}, prev);          // runs under this tile's MFMAs
+        prev = acc;
+        pipe.template arrive<fwd_younger<N, SAVE>(STAGE0 + nt)>();
+    });
+    finish(IC<NT - 1>{}, prev);
+#undef NERF_FS
 }
 
 // grid = nblk / 4 workgroups of 512 threads; every buffer indexed by block is allocated for nblk (a
@@ -300,14 +407,12 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     __syncthreads();
 
     WeightPipe pipe;
-    pipe.src = (const char*)a.wfwd;
+    pipe.src = pipe.base = (const char*)a.wfwd;
     pipe.slot_bytes = N::SLOT_KS * 1024;
     pipe.ring = (LDS_AS char*)(smem + N::C_TOTAL * 4);
-    pipe.cur = 1;
     pipe.wave = wave;
     pipe.lane = lane;
-    pipe.template prefetch<N::DKS>(0);
-    pipe.template arrive<0>();
+    pipe.template prime<fwd_stage<N, SAVE>(0).ks, fwd_stage<N, SAVE>(1).ks, fwd_stage<N, SAVE>(2).ks, fwd_stage<N, SAVE>(3).ks>();
 
     float hd_density[4], hd_colour[4], ln[2] = {0.f, 0.f};
     bf16x8 xa[N::HKS], xb[N::HKS], none[1];
@@ -315,21 +420,22 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     constexpr int HKS = N::HKS, HT = N::HT;
     const float* bias = cst + N::C_BIAS;
     // density_net0: enc -> X0 -> X1 -> X2 -> X3
-    fwd_layer<N, SAVE, HT, 0, N::DKS, HKS, true, EPI_PLAIN>(pipe, none, enc, xa, bias + 0 * N::HP, h, a.tx[0], a.mask[0], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 1 * N::HP, h, a.tx[1], a.mask[1], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 2 * N::HP, h, a.tx[2], a.mask[2], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, HT, HKS, 0, HKS + N::DKS, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 3 * N::HP, h, a.tx[3], a.mask[3], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 0 * HT, HT, 0, N::DKS, true, EPI_PLAIN>(pipe, none, enc, xa, bias + 0 * N::HP, h, a.tx[0], a.mask[0], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 1 * HT, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 1 * N::HP, h, a.tx[1], a.mask[1], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 2 * HT, HT, HKS, 0, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 2 * N::HP, h, a.tx[2], a.mask[2], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 3 * HT, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 3 * N::HP, h, a.tx[3], a.mask[3], b32, P, hd_density, ln);
     // density_net1: [X3 | enc] -> X4 -> ... -> X7 (trunk output)
-    fwd_layer<N, SAVE, HT, HKS, N::DKS, HKS, true, EPI_PLAIN>(pipe, xb, enc, xa, bias + 4 * N::HP, h, a.tx[4], a.mask[4], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 5 * N::HP, h, a.tx[5], a.mask[5], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 6 * N::HP, h, a.tx[6], a.mask[6], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, HT, HKS, 0, HKS, true, EPI_TRUNK>(pipe, xa, none, xb, bias + 7 * N::HP, h, a.tx[7], a.mask[7], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 4 * HT, HT, HKS, N::DKS, true, EPI_PLAIN>(pipe, xb, enc, xa, bias + 4 * N::HP, h, a.tx[4], a.mask[4], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 5 * HT, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 5 * N::HP, h, a.tx[5], a.mask[5], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 6 * HT, HT, HKS, 0, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 6 * N::HP, h, a.tx[6], a.mask[6], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 7 * HT, HT, HKS, 0, true, EPI_TRUNK>(pipe, xa, none, xb, bias + 7 * N::HP, h, a.tx[7], a.mask[7], b32, P, hd_density, ln);
     // final_density as one more output tile on X7 (row 0), then rgb_net0 (no activation): X7 -> X8
-    fwd_layer<N, SAVE, 1, HKS, 0, HKS, false, EPI_HEAD>(pipe, xb, none, xw, cst + N::C_BIASD, h, nullptr, nullptr, b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, HT, HKS, 0, HKS + N::VKS, false, EPI_PLAIN>(pipe, xb, none, xa, bias + 8 * N::HP, h, a.tx[8], nullptr, b32, P, hd_colour, ln);
+    fwd_layer<N, SAVE, 8 * HT, 1, HKS, 0, false, EPI_HEAD>(pipe, xb, none, xw, cst + N::C_BIASD, h, nullptr, nullptr, b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 8 * HT + 1, HT, HKS, 0, false, EPI_PLAIN>(pipe, xb, none, xa, bias + 8 * N::HP, h, a.tx[8], nullptr, b32, P, hd_colour, ln);
     // rgb_net1: [X8 | view] -> X9 ; final_rgb (+ final_angle) as one output tile on X9 (rows 0..4)
-    fwd_layer<N, SAVE, N::WT, HKS, N::VKS, N::WKS, true, EPI_PLAIN>(pipe, xa, view, xw, cst + N::C_BIAS9, h, a.tx[9], a.mask[9], b32, P, hd_colour, ln);
-    fwd_layer<N, SAVE, 1, N::WKS, 0, 0, false, EPI_HEAD>(pipe, xw, none, xa, cst + N::C_BIASH, h, nullptr, nullptr, b32, P, hd_colour, ln);
+    fwd_layer<N, SAVE, 9 * HT + 1, N::WT, HKS, N::VKS, true, EPI_PLAIN>(pipe, xa, view, xw, cst + N::C_BIAS9, h, a.tx[9], a.mask[9], b32, P, hd_colour, ln);
+    fwd_layer<N, SAVE, 9 * HT + 1 + N::WT, 1, N::WKS, 0, false, EPI_HEAD>(pipe, xw, none, xa, cst + N::C_BIASH, h, nullptr, nullptr, b32, P, hd_colour, ln);
+    static_assert(fwd_stage<N, SAVE>(9 * HT + 2 + N::WT).ks == 0, "stage table out of step");
 
     // outputs.  Lane half 0 holds rows 0..3 of a head tile, half 1 rows 4..7.
     const float* sc = cst + N::C_SC;
@@ -382,19 +488,38 @@ struct MlpBwdArgs {
 };
 
 // One backward layer: NT output tiles (features of the layer INPUT), reduction over KS_M k-steps of
-// `gm` (the layer's dY) then KS_E of `ge`.  MASKED: zero the units whose saved pre-activation was negative.
-template <class N, int NT, int KS_M, int KS_E, int NEXT_KS, bool MASKED, int KM, int KE, int KO>
+// `gm` (the layer's dY) then KS_E of `ge`.  MASKED: zero the units whose saved pre-activation was negative,
+// by the sign words in `keepw` (loaded a layer ahead, so that the load is old by the time it is waited for
+// and does not drain the fetches and stores queued behind it).  The first stage loads the next layer's words.
+template <class N, int STAGE0, int NT, int KS_M, int KS_E, bool MASKED, int NW_NEXT, int KM, int KE, int KO, int KW, int KWN>
 __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[KM], const bf16x8 (&ge)[KE],
-                                          bf16x8 (&out)[KO], const unsigned* mask, bf16x8* tdy, int64_t b32,
-                                          const bf16x8 (&P)[2]) {
+                                          bf16x8 (&out)[KO], const unsigned (&keepw)[KW], const unsigned* next_mask,
+                                          unsigned (&nextw)[KWN], bf16x8* tdy, int64_t b32, const bf16x8 (&P)[2]) {
     constexpr int KS = KS_M + KS_E;
     const int lane = pipe.lane;
-    unsigned keep = 0;
+#define NERF_BS(i) bwd_stage<N>(i)
+    static_assert(NERF_BS(STAGE0).ks == KS && NERF_BS(STAGE0 + NT - 1).ks == KS && NERF_BS(STAGE0).xloads == NW_NEXT,
+                  "stage table out of step");
+    auto finish = [&](auto ntc, const f32x16& acc) __attribute__((always_inline)) {
+        constexpr int nt = decltype(ntc)::value;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        if (nt + 1 < NT) pipe.template prefetch<KS>(pipe.cur ^ 1);
-        else pipe.template prefetch<NEXT_KS>(pipe.cur ^ 1);
-        if (MASKED && (nt & 1) == 0) keep = ~mask[(b32 * ((NT + 1) / 2) + (nt >> 1)) * 64 + lane];
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (__bf16)acc[8 * s + j];
+            if (MASKED) o = piece_apply_keep(o, ~keepw[MASKED ? nt >> 1 : 0] >> (8 * (nt & 1)), s);
+            out[2 * nt + s] = o;
+        }
+        emit_tfrag(tdy, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
+    };
+    f32x16 prev;
+    static_for<0, NT>([&](auto ntc) __attribute__((always_inline)) {
+        constexpr int nt = decltype(ntc)::value;
+        pipe.template prefetch<NERF_BS(STAGE0 + nt + kRing - 1).ks>();
+        if (nt == 0) {
+#pragma unroll
+            for (int i = 0; i < NW_NEXT; ++i) nextw[i] = next_mask[(b32 * NW_NEXT + i) * 64 + lane];
+        }
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -404,17 +529,12 @@ __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[K
             const bf16x8 b = ks < KS_M ? gm[ks < KS_M ? ks : 0] : ge[ks >= KS_M ? ks - KS_M : 0];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (__bf16)acc[8 * s + j];
-            if (MASKED) o = piece_apply_keep(o, keep >> (8 * (nt & 1)), s);
-            out[2 * nt + s] = o;
-        }
-        emit_tfrag(tdy, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
-        pipe.template arrive<2>();
-    }
+        if constexpr (nt > 0) finish(IC<nt - 1>{}, prev);          // runs under this tile's MFMAs
+        prev = acc;
+        pipe.template arrive<bwd_younger<N>(STAGE0 + nt)>();
+    });
+    finish(IC<NT - 1>{}, prev);
+#undef NERF_BS
 }
 
 template <class N>
@@ -432,6 +552,8 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
     const bool ok = m < a.M;
     bf16x8 P[2];
     make_perm(P, lane);
+    constexpr int HKS = N::HKS, HT = N::HT, WKS = N::WKS, WT = N::WT;
+    constexpr int HW = (HT + 1) / 2, WW = (WT + 1) / 2;       // sign words per lane per layer
 
     // gradient w.r.t. the pre-sigmoid head outputs and the raw density, as one-k-step B operands:
     // rows 0..3 of a head tile are elements 0..3 of lane half 0, row 4 is element 0 of lane half 1.
@@ -446,35 +568,36 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
         }
         dd[0] = (__bf16)a.g_density[m];
     }
+    unsigned kw9[WW], kwa[HW], kwb[HW], nokw[1] = {0u};
+#pragma unroll
+    for (int i = 0; i < WW; ++i) kw9[i] = a.mask[9][(b32 * WW + i) * 64 + lane];
     emit_tfrag(a.tdy_hd, b32, 1, 0, lane, dz, zero, P);
     emit_tfrag(a.tdy_dens, b32, 1, 0, lane, dd, zero, P);
 
     WeightPipe pipe;
-    pipe.src = (const char*)a.wbwd;
+    pipe.src = pipe.base = (const char*)a.wbwd;
     pipe.slot_bytes = N::BWD_SLOT_KS * 1024;
     pipe.ring = (LDS_AS char*)smem;
-    pipe.cur = 1;
     pipe.wave = wave;
     pipe.lane = lane;
-    pipe.template prefetch<1>(0);
-    pipe.template arrive<0>();
+    pipe.template prime<bwd_stage<N>(0).ks, bwd_stage<N>(1).ks, bwd_stage<N>(2).ks, bwd_stage<N>(3).ks>();
 
-    constexpr int HKS = N::HKS, HT = N::HT, WKS = N::WKS;
     bf16x8 ga[HKS], gb[HKS], gw[WKS], none[1], dzv[1] = {dz}, ddv[1] = {dd};
     // heads^T: dX9 = Wh^T dz, masked by X9 > 0 -> dY9
-    bwd_layer<N, N::WT, 1, 0, WKS, true>(pipe, dzv, none, gw, a.mask[9], a.tdy[9], b32, P);
+    bwd_layer<N, 0, WT, 1, 0, true, 0>(pipe, dzv, none, gw, kw9, nullptr, nokw, a.tdy[9], b32, P);
     // rgb_net1^T (rows of X8 only): dY8 = W9[:, :H]^T dY9   (rgb_net0 has no activation)
-    bwd_layer<N, HT, WKS, 0, HKS + 1, false>(pipe, gw, none, ga, nullptr, a.tdy[8], b32, P);
+    bwd_layer<N, WT, HT, WKS, 0, false, HW>(pipe, gw, none, ga, nokw, a.mask[7], kwa, a.tdy[8], b32, P);
     // [rgb_net0 ; density head]^T: dX7 = W8^T dY8 + wd^T dd, masked by X7 > 0 -> dY7
-    bwd_layer<N, HT, HKS, 1, HKS, true>(pipe, ga, ddv, gb, a.mask[7], a.tdy[7], b32, P);
-    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, gb, none, ga, a.mask[6], a.tdy[6], b32, P);
-    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, ga, none, gb, a.mask[5], a.tdy[5], b32, P);
-    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, gb, none, ga, a.mask[4], a.tdy[4], b32, P);
+    bwd_layer<N, WT + 1 * HT, HT, HKS, 1, true, HW>(pipe, ga, ddv, gb, kwa, a.mask[6], kwb, a.tdy[7], b32, P);
+    bwd_layer<N, WT + 2 * HT, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[5], kwa, a.tdy[6], b32, P);
+    bwd_layer<N, WT + 3 * HT, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[4], kwb, a.tdy[5], b32, P);
+    bwd_layer<N, WT + 4 * HT, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[3], kwa, a.tdy[4], b32, P);
     // density_net1.0^T (rows of X3 only; the encoding needs no gradient)
-    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, ga, none, gb, a.mask[3], a.tdy[3], b32, P);
-    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, gb, none, ga, a.mask[2], a.tdy[2], b32, P);
-    bwd_layer<N, HT, HKS, 0, HKS, true>(pipe, ga, none, gb, a.mask[1], a.tdy[1], b32, P);
-    bwd_layer<N, HT, HKS, 0, 0, true>(pipe, gb, none, ga, a.mask[0], a.tdy[0], b32, P);
+    bwd_layer<N, WT + 5 * HT, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[2], kwb, a.tdy[3], b32, P);
+    bwd_layer<N, WT + 6 * HT, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[1], kwa, a.tdy[2], b32, P);
+    bwd_layer<N, WT + 7 * HT, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[0], kwb, a.tdy[1], b32, P);
+    bwd_layer<N, WT + 8 * HT, HT, HKS, 0, true, 0>(pipe, gb, none, ga, kwb, nullptr, nokw, a.tdy[0], b32, P);
+    static_assert(bwd_stage<N>(WT + 9 * HT).ks == 0, "stage table out of step");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -555,7 +678,7 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(WgradArgs a) {
                 const char* src = (const char*)a.a;
                 LDS_AS char* dst = scratch + wave * 1024;
                 if (i < n && p < P) {
-                    src = p < a.NT ? (const char*)(a.a + (q * a.NT + p) * 64) : (const char*)(a.b + (q * a.KT + (p - a.NT)) * 64);
+                    src = p < a.NT ? (const char*)(a.a + tfrag_piece(q, a.NT, p) * 64) : (const char*)(a.b + tfrag_piece(q, a.KT, p - a.NT) * 64);
                     dst = slot + p * 1024;
                 }
                 __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + lane * 16), (LDS_AS void*)dst, 16, 0, 0);
@@ -976,7 +1099,7 @@ extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const f
 template <class N>
 static int launch_bwd(const MlpBwdArgs& a, hipStream_t st) {
     static bool attr_set = false;
-    constexpr int lds = 2 * N::BWD_SLOT_KS * 1024;
+    constexpr int lds = N::BWD_LDS;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)mlp_bwd_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
             hipSuccess)

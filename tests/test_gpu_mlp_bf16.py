@@ -77,16 +77,16 @@ def frag_to_dense(buf, F, M):
 
 
 def tfrag_to_dense(buf, F, M):
-    """Unpack a transposed-fragment buffer [block of 32][2][F/32][64][8] to a dense fp32 [M, F] matrix."""
+    """Unpack a transposed-fragment buffer [16-sample k-step][F/32 tiles][64 lanes][8] to a dense fp32 [M, F]
+    matrix: lane 32*hh + n holds feature n of the tile, element j sample 8*(j>>2) + 4*hh + (j&3) of the k-step."""
     NT = F // 32
-    nb = buf.numel() // (2 * NT * 1024)
-    x = buf.view(torch.bfloat16).reshape(nb, 2, NT, 2, 32, 8).float().cpu()
-    out = torch.zeros(nb, 32, NT, 32)
-    for s in range(2):
-        for hh in range(2):
-            for j in range(8):
-                out[:, 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)] = x[:, s, :, hh, :, j]
-    return out.reshape(nb * 32, F)[:M]
+    nq = buf.numel() // (NT * 1024)
+    x = buf.view(torch.bfloat16).reshape(nq, NT, 2, 32, 8).float().cpu()
+    out = torch.zeros(nq, 16, NT, 32)                  # k-step, sample in k-step, tile, feature
+    for hh in range(2):
+        for j in range(8):
+            out[:, 8 * (j >> 2) + 4 * hh + (j & 3)] = x[:, :, hh, :, j]
+    return out.reshape(nq * 16, F)[:M]
 
 
 def fro(a, b):
