@@ -39,6 +39,18 @@ def make_cfg(precision='bf16'):
                            mlp_precision=precision)
 
 
+def pmc_traffic(kernel, rays=65536):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same workload
+    (profiles/r01_pmc_traffic.json, made by tools/pmc_summary.py); None if absent or for another batch size."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    if rays != 65536 or not os.path.exists(path):
+        return None
+    for name, rec in json.load(open(path))['kernels'].items():
+        if name == kernel or name.startswith(kernel + '<'):
+            return rec['traffic_bytes_per_launch']
+    return None
+
+
 def cpu_baseline(budget_rays=192, threads=None):
     """The CPU oracle (fp32 restatement of the reference path) on a bounded sample of the same workload:
     fwd + loss + bwd at 64+128 samples per ray, all host cores torch gives us."""
@@ -153,20 +165,22 @@ def main():
                        'loss': float(loss)},
         }
         if prof:
-            fam = {k: v['ms'] / args.steps for k, v in prof.items()}
-            out['kernel_ms_per_step'] = {k: round(v, 3) for k, v in fam.items()}
-            dom = max(fam, key=fam.get)
+            per = {k: v['ms'] / args.steps for k, v in prof.items()}
+            out['kernel_ms_per_step'] = {k: round(v, 3) for k, v in per.items()}
+            dom = max(per, key=per.get)                         # the kernel (symbol) with the most time per step
             r = prof[dom]
-            if dom == 'mlp_wgrad':           # HBM-bound: algorithmic operand bytes / time
+            avg_ms = r['ms'] / r['calls']
+            if dom.startswith('mlp_wgrad'):      # streams its operands once from HBM: bytes / time
                 achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
-                out['roofline'] = {'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                                   'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                                   'calls_per_step': r['calls'] / args.steps}
-            else:                             # MFMA-bound: algorithmic FLOPs / time
+                roof = {'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': achieved / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': r['bytes'] / r['calls']}
+            else:                                 # weights in LDS, activations in registers: FLOPs / time
                 achieved = r['flops'] / (r['ms'] * 1e-3) / 1e12
-                out['roofline'] = {'kernel': dom, 'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS,
-                                   'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'traffic': None,
-                                   'calls_per_step': r['calls'] / args.steps}
+                roof = {'kernel': dom, 'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS,
+                        'algorithmic_flops_per_launch': r['flops'] / r['calls']}
+            roof.update(avg_launch_ms=avg_ms, launches_per_step=r['calls'] / args.steps, traffic=pmc_traffic(dom, args.rays) if args.chunk >= args.rays else None)
+            out['roofline'] = roof
             mlp_flops = sum(prof[k]['flops'] for k in prof if k.startswith('mlp_'))
             mlp_ms = sum(prof[k]['ms'] for k in prof if k.startswith('mlp_'))
             if mlp_ms > 0:

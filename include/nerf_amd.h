@@ -230,6 +230,10 @@ int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, int64_t n_samples,
 int nerf_mlp_wgrad(const void* dy_tfrag, int n_feat, const void* x_tfrag, int k_feat, int64_t n_samples,
                    float* G, int ld, int col0, int n_true, int k_true, float* gb, int grid_hint, void* stream);
 
+/* The mlp_wgrad_kernel<tn, tk> instantiation nerf_mlp_wgrad launches for these padded feature counts, so a
+ * profiler can label launches by kernel symbol.  (No reference counterpart: measurement support.) */
+int nerf_mlp_wgrad_config(int n_feat, int k_feat, int* tn, int* tk);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1154,6 +1154,31 @@ static int launch_wgrad(const WgradArgs& a, unsigned grid, size_t lds, hipStream
     return nerf_launch_status();
 }
 
+// Split the NT x KT output tiles over the 4 waves (WN x WK) so that the per-wave block fits an instantiated
+// template (tn x tk accumulator tiles) with the fewest tiles.
+static bool wgrad_config(int NT, int KT, int* WN, int* WK, int* tn, int* tk) {
+    static const int kSplit[3][2] = {{2, 2}, {4, 1}, {1, 4}};
+    static const int kTmpl[6][2] = {{1, 1}, {1, 2}, {1, 4}, {2, 2}, {2, 4}, {4, 4}};
+    int best = 1 << 30;
+    *tn = *tk = 0;
+    for (const auto& sp : kSplit) {
+        const int ntw = (NT + sp[0] - 1) / sp[0], ktw = (KT + sp[1] - 1) / sp[1];
+        for (const auto& t : kTmpl)
+            if (t[0] >= ntw && t[1] >= ktw && t[0] * t[1] < best) {
+                best = t[0] * t[1]; *tn = t[0]; *tk = t[1]; *WN = sp[0]; *WK = sp[1];
+            }
+    }
+    return *tn != 0;
+}
+
+// Which mlp_wgrad_kernel<tn, tk> instantiation nerf_mlp_wgrad launches for these feature counts (profilers
+// label launches with it).
+extern "C" int nerf_mlp_wgrad_config(int n_feat, int k_feat, int* tn, int* tk) {
+    int wn, wk;
+    NERF_REQUIRE(tn && tk && n_feat > 0 && k_feat > 0 && n_feat % 32 == 0 && k_feat % 32 == 0);
+    return wgrad_config(n_feat / 32, k_feat / 32, &wn, &wk, tn, tk) ? NERF_OK : NERF_ERR_SIZE;
+}
+
 // G[n_true, ld] (+= at column col0, k_true columns) and gb[n_true] (nullable) accumulate dY^T X over
 // n_samples rows; dy_tfrag has n_feat features, x_tfrag k_feat features (multiples of 32, <= 256).
 extern "C" int nerf_mlp_wgrad(const void* dy_tfrag, int n_feat, const void* x_tfrag, int k_feat, int64_t n_samples,
@@ -1168,19 +1193,8 @@ extern "C" int nerf_mlp_wgrad(const void* dy_tfrag, int n_feat, const void* x_tf
     a.nq = ((n_samples + 255) / 256) * 16;            // 16-sample k-steps, whole 256-sample workgroup tiles
     a.NT = n_feat / 32;
     a.KT = k_feat / 32;
-    // split the output tiles over the 4 waves (WN x WK) so that the per-wave block fits an instantiated
-    // template with the fewest accumulator tiles
-    static const int kSplit[3][2] = {{2, 2}, {4, 1}, {1, 4}};
-    static const int kTmpl[6][2] = {{1, 1}, {1, 2}, {1, 4}, {2, 2}, {2, 4}, {4, 4}};
-    int best = 1 << 30, tn = 0, tk = 0;
-    for (const auto& sp : kSplit) {
-        const int ntw = (a.NT + sp[0] - 1) / sp[0], ktw = (a.KT + sp[1] - 1) / sp[1];
-        for (const auto& t : kTmpl)
-            if (t[0] >= ntw && t[1] >= ktw && t[0] * t[1] < best) {
-                best = t[0] * t[1]; tn = t[0]; tk = t[1]; a.WN = sp[0]; a.WK = sp[1];
-            }
-    }
-    if (tn == 0) return NERF_ERR_SIZE;
+    int tn = 0, tk = 0;
+    if (!wgrad_config(a.NT, a.KT, &a.WN, &a.WK, &tn, &tk)) return NERF_ERR_SIZE;
     a.G = G; a.ld = ld; a.col0 = col0; a.n_true = n_true; a.k_true = k_true; a.gb = gb;
     unsigned grid = grid_hint > 0 ? (unsigned)grid_hint : 256u;
     if ((int64_t)grid > a.nq) grid = (unsigned)a.nq;

@@ -21,6 +21,7 @@ _lib.register('nerf_mlp_fwd', c_int, [POINTER(MlpDims), _P, _P, _P, _P, c_int64,
 
 _lib.register('nerf_mlp_bwd', c_int, [POINTER(MlpDims), _P, c_int64, _P, _P, _P, _P, _P, _P, POINTER(c_void_p),
                                       POINTER(c_void_p), _P])
+_lib.register('nerf_mlp_wgrad_config', c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)])
 _lib.register('nerf_mlp_wgrad', c_int, [_P, c_int, _P, c_int, c_int64, _P, c_int, c_int, c_int, c_int, _P, c_int, _P])
 
 STREAMED = (['density_net0.%d' % i for i in (0, 2, 4, 6)] + ['density_net1.%d' % i for i in (0, 2, 4, 6)]
@@ -173,7 +174,7 @@ def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False):
         acts += [torch.empty(nblk * pk.DT * 4096, dtype=torch.uint8, device=dev),
                  torch.empty(nblk * pk.VT * 4096, dtype=torch.uint8, device=dev)]
         arr = (c_void_p * 22)(*[a.data_ptr() if a is not None else None for a in acts])
-    with profiling.timed('mlp_fwd', flops=pk.fwd_flops * n_samples):
+    with profiling.timed('mlp_fwd_kernel', flops=pk.fwd_flops * n_samples):
         check(lib().nerf_mlp_fwd(ctypes.byref(pk.dims), _raw(pk.wfwd), ptr(pk.consts), _raw(enc), _raw(view),
                                  n_samples, ray_div, n_rays, arr, ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
                                  ptr(ln_stats), stream()))
@@ -189,25 +190,39 @@ def mlp_backward(pk, acts, n_samples, g_density, g_rgb, raw_rgb):
     a_arr = (c_void_p * 22)(*[a.data_ptr() if a is not None else None for a in acts])
     d_arr = (c_void_p * 12)(*[d.data_ptr() for d in dys])
     g_density, g_rgb = f32c(g_density).reshape(-1), f32c(g_rgb).reshape(-1, 3)
-    with profiling.timed('mlp_bwd_dx', flops=pk.bwd_dx_flops * n_samples):
+    with profiling.timed('mlp_bwd_kernel', flops=pk.bwd_dx_flops * n_samples):
         check(lib().nerf_mlp_bwd(ctypes.byref(pk.dims), _raw(pk.wbwd), n_samples, ptr(g_density), ptr(g_rgb), None,
                                  ptr(raw_rgb), None, None, a_arr, d_arr, stream()))
     return dys
 
 
+_WGRAD_KERNEL = {}
+
+
+def wgrad_kernel_name(n_feat, k_feat):
+    """Symbol of the kernel instantiation that handles these feature counts."""
+    key = (n_feat, k_feat)
+    if key not in _WGRAD_KERNEL:
+        tn, tk = c_int(), c_int()
+        check(lib().nerf_mlp_wgrad_config(n_feat, k_feat, ctypes.byref(tn), ctypes.byref(tk)))
+        _WGRAD_KERNEL[key] = 'mlp_wgrad_kernel<%d, %d>' % (tn.value, tk.value)
+    return _WGRAD_KERNEL[key]
+
+
 def _wgrad(dy, n_feat, x, k_feat, n_samples, G, col0, n_true, k_true, gb):
-    check(lib().nerf_mlp_wgrad(_raw(dy), n_feat, _raw(x), k_feat, n_samples, ptr(G), G.stride(0), col0, n_true, k_true,
-                               ptr(gb), 0, stream()))
+    # algorithmic work of the launch: every operand byte once, 2 FLOP per true multiply-add
+    with profiling.timed(wgrad_kernel_name(n_feat, k_feat), flops=2.0 * n_true * k_true * n_samples,
+                         bytes_=2.0 * (n_feat + k_feat) * n_samples):
+        check(lib().nerf_mlp_wgrad(_raw(dy), n_feat, _raw(x), k_feat, n_samples, ptr(G), G.stride(0), col0, n_true,
+                                   k_true, ptr(gb), 0, stream()))
 
 
 def mlp_weight_grads(pk, acts, dys, n_samples, grads):
     """Accumulate all weight / bias gradients into `grads` (name -> zero-initialised or running fp32 tensor)."""
-    M = n_samples
-    with profiling.timed('mlp_wgrad', flops=pk.wgrad_flops * M, bytes_=pk.wgrad_bytes * M):
-        for di, nf, xs, kf, name, col0, n_true, k_true, with_bias in _wgrad_plan(pk):
-            x = acts[20] if xs == 'enc' else acts[21] if xs == 'view' else acts[xs[1]]
-            _wgrad(dys[di], nf, x, kf, M, grads[name + '.weight'], col0, n_true, k_true,
-                   grads[name + '.bias'] if with_bias else None)
+    for di, nf, xs, kf, name, col0, n_true, k_true, with_bias in _wgrad_plan(pk):
+        x = acts[20] if xs == 'enc' else acts[21] if xs == 'view' else acts[xs[1]]
+        _wgrad(dys[di], nf, x, kf, n_samples, grads[name + '.weight'], col0, n_true, k_true,
+               grads[name + '.bias'] if with_bias else None)
 
 
 PARAM_NAMES = [n + s for n in STREAMED + ['final_density.0', 'final_rgb.0'] for s in ('.weight', '.bias')]
