@@ -54,6 +54,19 @@ __device__ __forceinline__ bf16x8 relu_bf16(bf16x8 x) {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// Eight fp32 accumulator values -> one bf16 piece, two per v_cvt_pk_bf16_f32 (round to nearest even).
+__device__ __forceinline__ bf16x8 pack_bf16x8(const f32x16& v, int first) {
+    u32x4 d;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x2 p = {v[first + 2 * q], v[first + 2 * q + 1]};
+        d[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2));
+    }
+    return __builtin_bit_cast(bf16x8, d);
+}
 
 // Sign bits of the 8 bf16 of piece s (0/1) of a tile: dword q of the piece lands on bits 4s+q (low half)
 // and 16+4s+q (high half) -- a tile's 16 units fill bits 0..7 and 16..23 of a word.
@@ -94,9 +107,7 @@ __device__ __forceinline__ void emit_tfrag(bf16x8* dst, int64_t b32, int NT, int
     t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, P[1], t, 0, 0, 0);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        bf16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (__bf16)t[8 * s + j];
+        const bf16x8 o = pack_bf16x8(t, 8 * s);
         __builtin_nontemporal_store(o, &dst[tfrag_piece(b32 * 2 + s, NT, nt) * 64 + lane]);
     }
 }
@@ -161,6 +172,10 @@ struct MlpFwdArgs {
 // A workgroup is 8 waves (two per SIMD); wave w owns the 32-sample column tile (w & 1) of block
 // 4*blockIdx + (w >> 1) and loads pieces w, w+8, ... of every stage.
 constexpr int kWaves = 8;
+#ifndef NERF_LDS_AHEAD
+#define NERF_LDS_AHEAD 6
+#endif
+constexpr int kLdsAhead = NERF_LDS_AHEAD;     // weight pieces in flight LDS -> registers per wave
 
 // Per-stage facts the pipeline's counted waits need.  A stage = one output tile: fetch weights kRing-1 stages
 // ahead, run the tile's MFMAs, and -- under those MFMAs -- finish the PREVIOUS tile (convert, activation,
@@ -285,8 +300,34 @@ struct WeightPipe {
         __builtin_amdgcn_sched_barrier(0);
         cur = (cur + 1) % kRing;
     }
-    __device__ __forceinline__ bf16x8 piece(int ks) const {
-        return *(const LDS_AS bf16x8*)(ring + cur * slot_bytes + ks * 1024 + lane * 16);
+    // acc += W_tile * X over the KS k-steps of the current slot; B operand of k-step ks = b(IC<ks>).  The LDS
+    // reads run kLdsAhead pieces ahead of the MFMAs behind counted lgkmcnt waits (LDS returns in order), so
+    // that a wave's MFMAs are not each held up by a full LDS round trip.
+    template <int KS, class B>
+    __device__ __forceinline__ void tile(f32x16& acc, B&& b) const {
+        constexpr int D = kLdsAhead < KS ? kLdsAhead : KS;
+        const unsigned addr = (unsigned)(size_t)(ring + cur * slot_bytes + lane * 16);
+        bf16x8 a[D];
+        tile_issue<0, D>(a, addr);
+        tile_step<KS, D, 0>(acc, a, addr, b);
+    }
+    template <int I, int D>
+    static __device__ __forceinline__ void tile_issue(bf16x8 (&a)[D], unsigned addr) {
+        if constexpr (I < D) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[I]) : "v"(addr), "n"(I * 1024));
+            tile_issue<I + 1, D>(a, addr);
+        }
+    }
+    template <int KS, int D, int ks, class B>
+    static __device__ __forceinline__ void tile_step(f32x16& acc, bf16x8 (&a)[D], unsigned addr, B& b) {
+        if constexpr (ks < KS) {
+            constexpr int later = (KS - 1 - ks) < (D - 1) ? (KS - 1 - ks) : (D - 1);     // reads issued after piece ks
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[ks % D]) : "n"(later));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D], b(IC<ks>{}), acc, 0, 0, 0);
+            if constexpr (ks + D < KS)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[ks % D]) : "v"(addr), "n"((ks + D) * 1024));
+            tile_step<KS, D, ks + 1>(acc, a, addr, b);
+        }
     }
 };
 
@@ -309,8 +350,15 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
 #define NERF_FS(i) fwd_stage<N, SAVE>(i)
     static_assert(NERF_FS(STAGE0).ks == KS && NERF_FS(STAGE0 + NT - 1).ks == KS, "stage table out of step");
     // finish tile nt from its accumulator: activation, bf16 B operand of the next layer, saved copies
-    auto finish = [&](auto ntc, const f32x16& acc) __attribute__((always_inline)) {
+    auto finish = [&](auto ntc, const f32x16& raw) __attribute__((always_inline)) {
         constexpr int nt = decltype(ntc)::value;
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {       // accumulator rows 8g + 4h .. + 3 of the tile
+            const f32x4 b = *(const f32x4*)(bias + nt * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[4 * g + q] = raw[4 * g + q] + b[q];
+        }
         if (EPI == EPI_HEAD) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) head[q] = acc[q];          // rows 4h .. 4h+3 of the tile
@@ -326,9 +374,7 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (__bf16)acc[8 * s + j];
+            bf16x8 o = pack_bf16x8(acc, 8 * s);
             if (kMask) signs |= piece_sign_bits(o, s) << (8 * (nt & 1));
             if (RELU) o = relu_bf16(o);
             out[2 * nt + s] = o;
@@ -345,17 +391,12 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
         pipe.template prefetch<NERF_FS(STAGE0 + nt + kRing - 1).ks>();
         f32x16 acc;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 b = *(const f32x4*)(bias + nt * 32 + 8 * g + 4 * h);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[4 * g + q] = b[q];
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 a = pipe.piece(ks);
-            const bf16x8 b = ks < KS_M ? xm[ks < KS_M ? ks : 0] : xe[ks >= KS_M ? ks - KS_M : 0];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-        }
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        pipe.template tile<KS>(acc, [&](auto kc) __attribute__((always_inline)) {
+            constexpr int ks = decltype(kc)::value;
+            if constexpr (ks < KS_M) return xm[ks];
+            else return xe[ks - KS_M];
+        });
         if constexpr (nt > 0) finish(IC<nt - 1>{}, prev);          // runs under this tile's MFMAs
         prev = acc;
         pipe.template arrive<fwd_younger<N, SAVE>(STAGE0 + nt)>();
@@ -504,9 +545,7 @@ __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[K
         constexpr int nt = decltype(ntc)::value;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (__bf16)acc[8 * s + j];
+            bf16x8 o = pack_bf16x8(acc, 8 * s);
             if (MASKED) o = piece_apply_keep(o, ~keepw[MASKED ? nt >> 1 : 0] >> (8 * (nt & 1)), s);
             out[2 * nt + s] = o;
         }
@@ -523,12 +562,11 @@ __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[K
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 a = pipe.piece(ks);
-            const bf16x8 b = ks < KS_M ? gm[ks < KS_M ? ks : 0] : ge[ks >= KS_M ? ks - KS_M : 0];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-        }
+        pipe.template tile<KS>(acc, [&](auto kc) __attribute__((always_inline)) {
+            constexpr int ks = decltype(kc)::value;
+            if constexpr (ks < KS_M) return gm[ks];
+            else return ge[ks - KS_M];
+        });
         if constexpr (nt > 0) finish(IC<nt - 1>{}, prev);          // runs under this tile's MFMAs
         prev = acc;
         pipe.template arrive<bwd_younger<N>(STAGE0 + nt)>();
