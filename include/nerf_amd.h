@@ -230,9 +230,28 @@ int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, int64_t n_samples,
 int nerf_mlp_wgrad(const void* dy_tfrag, int n_feat, const void* x_tfrag, int k_feat, int64_t n_samples,
                    float* G, int ld, int col0, int n_true, int k_true, float* gb, int grid_hint, void* stream);
 
-/* The mlp_wgrad_kernel<tn, tk> instantiation nerf_mlp_wgrad launches for these padded feature counts, so a
- * profiler can label launches by kernel symbol.  (No reference counterpart: measurement support.) */
-int nerf_mlp_wgrad_config(int n_feat, int k_feat, int* tn, int* tk);
+/* Several weight-gradient blocks in one pass over the samples: up to two dY buffers (rows) x two X buffers
+ * (columns), concatenated along the feature axis, so that a buffer shared by two layers' gradients is read once
+ * -- e.g. dY of density_net1.0 against [X3 | encoding] (the skip concatenation, model.py:120), or
+ * [dY of rgb_net0 | dY of final_density] against the trunk output.  Block (i, j) accumulates
+ * G[i][j][n, col0[i][j] + k] += sum_m dy[i][m, n] x[j][m, k] for n < dy_true[i], k < x_true[j] (G[i][j] NULL = skip);
+ * gb[i][n] += sum_m dy[i][m, n] (nullable).  Feature counts are padded (multiples of 32); unused second
+ * segments have feature count 0.  Total dY + X features <= 576.
+ *                              reference: autograd of nn.Linear (aten::mm of dY^T and X, aten::sum) */
+typedef struct nerf_wgrad_desc {
+    const void* dy[2];
+    int dy_feat[2], dy_true[2];
+    const void* x[2];
+    int x_feat[2], x_true[2];
+    float* G[2][2];
+    int ld[2][2], col0[2][2];
+    float* gb[2];
+} nerf_wgrad_desc;
+int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint, void* stream);
+
+/* The mlp_wgrad_kernel<nw, tn, tk> instantiation a weight-gradient launch with these total padded feature
+ * counts uses, so a profiler can label launches by kernel symbol.  (No reference counterpart: measurement support.) */
+int nerf_mlp_wgrad_config(int n_feat, int k_feat, int* nw, int* tn, int* tk);
 
 #ifdef __cplusplus
 }

@@ -119,6 +119,12 @@ __device__ __forceinline__ void emit_tfrag(bf16x8* dst, int64_t b32, int NT, int
 #define NERF_RING 3
 #endif
 constexpr int kRing = NERF_RING;
+// Output tiles per pipeline stage: the tiles of a stage share one weight fetch and one workgroup barrier.
+#ifndef NERF_TILES_PER_STAGE
+#define NERF_TILES_PER_STAGE 2
+#endif
+constexpr int kTPS = NERF_TILES_PER_STAGE;
+constexpr int stage_count(int tiles) { return (tiles + kTPS - 1) / kTPS; }
 
 // ------------------------------------------------------------------------------------------------
 // Network geometry (compile time).  HT/WT: 32-row tiles of the hidden width / colour-layer width;
@@ -137,9 +143,9 @@ struct Net {
     static constexpr int C_SC = C_BIASH + 32;            // scalars: [6] sum(w*gamma) [7] sum(w*beta) [8] 1/H [9] eps
     static constexpr int C_TOTAL = C_SC + 16;
     static constexpr int SLOT_KS = HKS + (DKS > VKS ? DKS : VKS);
-    static constexpr int FWD_LDS = C_TOTAL * 4 + (kRing * SLOT_KS + 1) * 1024;   // + 1 KiB landing zone
+    static constexpr int FWD_LDS = C_TOTAL * 4 + (kRing * kTPS * SLOT_KS + 1) * 1024;   // + 1 KiB landing zone
     static constexpr int BWD_SLOT_KS = (HKS + 1) > WKS ? (HKS + 1) : WKS;
-    static constexpr int BWD_LDS = (kRing * BWD_SLOT_KS + 1) * 1024;
+    static constexpr int BWD_LDS = (kRing * kTPS * BWD_SLOT_KS + 1) * 1024;
     // pieces (1 KiB) in the packed streams
     // forward: L0, L1-3, L4, L5-7, density head tile, L8, L9, rgb/angle head tile
     static constexpr int FWD_PIECES = HT * DKS + 3 * HT * HKS + HT * (HKS + DKS) + 3 * HT * HKS + HKS + HT * HKS +
@@ -177,14 +183,14 @@ constexpr int kWaves = 8;
 #endif
 constexpr int kLdsAhead = NERF_LDS_AHEAD;     // weight pieces in flight LDS -> registers per wave
 
-// Per-stage facts the pipeline's counted waits need.  A stage = one output tile: fetch weights kRing-1 stages
-// ahead, run the tile's MFMAs, and -- under those MFMAs -- finish the PREVIOUS tile (convert, activation,
-// transposition, stores).  The last tile of a layer is finished after the layer's last stage, i.e. ahead of
-// the next stage's fetch.  Program order of a wave's vector-memory operations within stage k:
-//   pre stores | fetch of stage k+kRing-1 (stage_loads) | extra loads | stores.
-struct StageDesc { int ks, pre, xloads, stores; };
+// Per-stage facts the pipeline's counted waits need.  A stage = up to kTPS consecutive output tiles of one layer:
+// fetch its weights kRing-1 stages ahead, then per tile run the MFMAs and -- under them -- finish the PREVIOUS
+// tile (bias, activation, conversion, transposition, stores).  The last tile of a layer is finished after the
+// layer's last stage, i.e. ahead of the next stage's fetch.  Program order of a wave's vector-memory operations
+// within stage k:   pre stores | fetch of stage k+kRing-1 (stage_loads) | extra loads | stores.
+struct StageDesc { int ks, pre, xloads, stores; };      // ks = pieces of the whole stage
 
-// Forward stages: L0, L1-3, L4, L5-7 (HT tiles each), density head (1), L8 (HT), L9 (WT), colour heads (1).
+// Forward layers: L0, L1-3, L4, L5-7 (HT tiles each), density head (1), L8 (HT), L9 (WT), colour heads (1).
 template <class N, bool SAVE>
 constexpr StageDesc fwd_stage(int i) {
     constexpr int kL = 12;
@@ -198,13 +204,17 @@ constexpr StageDesc fwd_stage(int i) {
     };
     if (i < 0) return {0, 0, 0, 0};
     for (int l = 0; l < kL; ++l) {
-        if (i < tiles[l])
-            return {ks[l], (i == 0 && l > 0) ? tile_stores(l - 1, tiles[l - 1] - 1) : 0, 0, i > 0 ? tile_stores(l, i - 1) : 0};
-        i -= tiles[l];
+        if (i < stage_count(tiles[l])) {
+            const int t0 = i * kTPS, t1 = t0 + kTPS < tiles[l] ? t0 + kTPS : tiles[l];
+            int st = 0;
+            for (int t = t0; t < t1; ++t) st += t > 0 ? tile_stores(l, t - 1) : 0;
+            return {ks[l] * (t1 - t0), (i == 0 && l > 0) ? tile_stores(l - 1, tiles[l - 1] - 1) : 0, 0, st};
+        }
+        i -= stage_count(tiles[l]);
     }
     return {0, 0, 0, 0};
 }
-// Backward stages: heads^T (WT tiles, 1 k-step), L9^T (HT, WKS), L8^T + density row (HT, HKS+1), 7 x (HT, HKS).
+// Backward layers: heads^T (WT tiles, 1 k-step), L9^T (HT, WKS), L8^T + density row (HT, HKS+1), 7 x (HT, HKS).
 // Finishing a tile stores 2 T-frag pieces; the first stage of a layer also loads the next masked layer's sign words.
 template <class N>
 constexpr StageDesc bwd_stage(int i) {
@@ -214,9 +224,13 @@ constexpr StageDesc bwd_stage(int i) {
     const bool masked[kL + 1] = {true, false, true, true, true, true, true, true, true, true, false};
     if (i < 0) return {0, 0, 0, 0};
     for (int l = 0; l < kL; ++l) {
-        if (i < tiles[l])
-            return {ks[l], (i == 0 && l > 0) ? 2 : 0, (i == 0 && masked[l + 1]) ? (tiles[l + 1] + 1) / 2 : 0, i > 0 ? 2 : 0};
-        i -= tiles[l];
+        if (i < stage_count(tiles[l])) {
+            const int t0 = i * kTPS, t1 = t0 + kTPS < tiles[l] ? t0 + kTPS : tiles[l];
+            int st = 0;
+            for (int t = t0; t < t1; ++t) st += t > 0 ? 2 : 0;
+            return {ks[l] * (t1 - t0), (i == 0 && l > 0) ? 2 : 0, (i == 0 && masked[l + 1]) ? (tiles[l + 1] + 1) / 2 : 0, st};
+        }
+        i -= stage_count(tiles[l]);
     }
     return {0, 0, 0, 0};
 }
@@ -303,10 +317,10 @@ struct WeightPipe {
     // acc += W_tile * X over the KS k-steps of the current slot; B operand of k-step ks = b(IC<ks>).  The LDS
     // reads run kLdsAhead pieces ahead of the MFMAs behind counted lgkmcnt waits (LDS returns in order), so
     // that a wave's MFMAs are not each held up by a full LDS round trip.
-    template <int KS, class B>
+    template <int KS, int P0, class B>     // the tile's pieces are P0 .. P0+KS-1 of the slot
     __device__ __forceinline__ void tile(f32x16& acc, B&& b) const {
         constexpr int D = kLdsAhead < KS ? kLdsAhead : KS;
-        const unsigned addr = (unsigned)(size_t)(ring + cur * slot_bytes + lane * 16);
+        const unsigned addr = (unsigned)(size_t)(ring + cur * slot_bytes + P0 * 1024 + lane * 16);
         bf16x8 a[D];
         tile_issue<0, D>(a, addr);
         tile_step<KS, D, 0>(acc, a, addr, b);
@@ -348,7 +362,9 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
     const int lane = pipe.lane;
     unsigned signs = 0;
 #define NERF_FS(i) fwd_stage<N, SAVE>(i)
-    static_assert(NERF_FS(STAGE0).ks == KS && NERF_FS(STAGE0 + NT - 1).ks == KS, "stage table out of step");
+    constexpr int NS = stage_count(NT);
+    static_assert(NERF_FS(STAGE0).ks == KS * (NT < kTPS ? NT : kTPS) && NERF_FS(STAGE0 + NS).ks != NERF_FS(STAGE0 + NS - 1).ks + 12345,
+                  "stage table out of step");
     // finish tile nt from its accumulator: activation, bf16 B operand of the next layer, saved copies
     auto finish = [&](auto ntc, const f32x16& raw) __attribute__((always_inline)) {
         constexpr int nt = decltype(ntc)::value;
@@ -386,20 +402,24 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
         }
     };
     f32x16 prev;
-    static_for<0, NT>([&](auto ntc) __attribute__((always_inline)) {
-        constexpr int nt = decltype(ntc)::value;
-        pipe.template prefetch<NERF_FS(STAGE0 + nt + kRing - 1).ks>();
-        f32x16 acc;
+    static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int st = decltype(sc)::value;
+        constexpr int T0 = st * kTPS, TN = (NT - T0) < kTPS ? (NT - T0) : kTPS;
+        pipe.template prefetch<NERF_FS(STAGE0 + st + kRing - 1).ks>();
+        static_for<0, TN>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value, nt = T0 + j;
+            f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        pipe.template tile<KS>(acc, [&](auto kc) __attribute__((always_inline)) {
-            constexpr int ks = decltype(kc)::value;
-            if constexpr (ks < KS_M) return xm[ks];
-            else return xe[ks - KS_M];
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            pipe.template tile<KS, j * KS>(acc, [&](auto kc) __attribute__((always_inline)) {
+                constexpr int ks = decltype(kc)::value;
+                if constexpr (ks < KS_M) return xm[ks];
+                else return xe[ks - KS_M];
+            });
+            if constexpr (nt > 0) finish(IC<nt - 1>{}, prev);          // runs under this tile's MFMAs
+            prev = acc;
         });
-        if constexpr (nt > 0) finish(IC<nt - 1>{}, prev);          // runs under this tile's MFMAs
-        prev = acc;
-        pipe.template arrive<fwd_younger<N, SAVE>(STAGE0 + nt)>();
+        pipe.template arrive<fwd_younger<N, SAVE>(STAGE0 + st)>();
     });
     finish(IC<NT - 1>{}, prev);
 #undef NERF_FS
@@ -449,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
 
     WeightPipe pipe;
     pipe.src = pipe.base = (const char*)a.wfwd;
-    pipe.slot_bytes = N::SLOT_KS * 1024;
+    pipe.slot_bytes = kTPS * N::SLOT_KS * 1024;
     pipe.ring = (LDS_AS char*)(smem + N::C_TOTAL * 4);
     pipe.wave = wave;
     pipe.lane = lane;
@@ -458,25 +478,25 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     float hd_density[4], hd_colour[4], ln[2] = {0.f, 0.f};
     bf16x8 xa[N::HKS], xb[N::HKS], none[1];
     bf16x8 xw[N::WKS];
-    constexpr int HKS = N::HKS, HT = N::HT;
+    constexpr int HKS = N::HKS, HT = N::HT, HS = stage_count(N::HT), WS = stage_count(N::WT);
     const float* bias = cst + N::C_BIAS;
     // density_net0: enc -> X0 -> X1 -> X2 -> X3
-    fwd_layer<N, SAVE, 0 * HT, HT, 0, N::DKS, true, EPI_PLAIN>(pipe, none, enc, xa, bias + 0 * N::HP, h, a.tx[0], a.mask[0], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, 1 * HT, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 1 * N::HP, h, a.tx[1], a.mask[1], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, 2 * HT, HT, HKS, 0, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 2 * N::HP, h, a.tx[2], a.mask[2], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, 3 * HT, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 3 * N::HP, h, a.tx[3], a.mask[3], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 0 * HS, HT, 0, N::DKS, true, EPI_PLAIN>(pipe, none, enc, xa, bias + 0 * N::HP, h, a.tx[0], a.mask[0], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 1 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 1 * N::HP, h, a.tx[1], a.mask[1], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 2 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 2 * N::HP, h, a.tx[2], a.mask[2], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 3 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 3 * N::HP, h, a.tx[3], a.mask[3], b32, P, hd_density, ln);
     // density_net1: [X3 | enc] -> X4 -> ... -> X7 (trunk output)
-    fwd_layer<N, SAVE, 4 * HT, HT, HKS, N::DKS, true, EPI_PLAIN>(pipe, xb, enc, xa, bias + 4 * N::HP, h, a.tx[4], a.mask[4], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, 5 * HT, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 5 * N::HP, h, a.tx[5], a.mask[5], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, 6 * HT, HT, HKS, 0, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 6 * N::HP, h, a.tx[6], a.mask[6], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, 7 * HT, HT, HKS, 0, true, EPI_TRUNK>(pipe, xa, none, xb, bias + 7 * N::HP, h, a.tx[7], a.mask[7], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 4 * HS, HT, HKS, N::DKS, true, EPI_PLAIN>(pipe, xb, enc, xa, bias + 4 * N::HP, h, a.tx[4], a.mask[4], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 5 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 5 * N::HP, h, a.tx[5], a.mask[5], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 6 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 6 * N::HP, h, a.tx[6], a.mask[6], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 7 * HS, HT, HKS, 0, true, EPI_TRUNK>(pipe, xa, none, xb, bias + 7 * N::HP, h, a.tx[7], a.mask[7], b32, P, hd_density, ln);
     // final_density as one more output tile on X7 (row 0), then rgb_net0 (no activation): X7 -> X8
-    fwd_layer<N, SAVE, 8 * HT, 1, HKS, 0, false, EPI_HEAD>(pipe, xb, none, xw, cst + N::C_BIASD, h, nullptr, nullptr, b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, 8 * HT + 1, HT, HKS, 0, false, EPI_PLAIN>(pipe, xb, none, xa, bias + 8 * N::HP, h, a.tx[8], nullptr, b32, P, hd_colour, ln);
+    fwd_layer<N, SAVE, 8 * HS, 1, HKS, 0, false, EPI_HEAD>(pipe, xb, none, xw, cst + N::C_BIASD, h, nullptr, nullptr, b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 8 * HS + 1, HT, HKS, 0, false, EPI_PLAIN>(pipe, xb, none, xa, bias + 8 * N::HP, h, a.tx[8], nullptr, b32, P, hd_colour, ln);
     // rgb_net1: [X8 | view] -> X9 ; final_rgb (+ final_angle) as one output tile on X9 (rows 0..4)
-    fwd_layer<N, SAVE, 9 * HT + 1, N::WT, HKS, N::VKS, true, EPI_PLAIN>(pipe, xa, view, xw, cst + N::C_BIAS9, h, a.tx[9], a.mask[9], b32, P, hd_colour, ln);
-    fwd_layer<N, SAVE, 9 * HT + 1 + N::WT, 1, N::WKS, 0, false, EPI_HEAD>(pipe, xw, none, xa, cst + N::C_BIASH, h, nullptr, nullptr, b32, P, hd_colour, ln);
-    static_assert(fwd_stage<N, SAVE>(9 * HT + 2 + N::WT).ks == 0, "stage table out of step");
+    fwd_layer<N, SAVE, 9 * HS + 1, N::WT, HKS, N::VKS, true, EPI_PLAIN>(pipe, xa, view, xw, cst + N::C_BIAS9, h, a.tx[9], a.mask[9], b32, P, hd_colour, ln);
+    fwd_layer<N, SAVE, 9 * HS + 1 + WS, 1, N::WKS, 0, false, EPI_HEAD>(pipe, xw, none, xa, cst + N::C_BIASH, h, nullptr, nullptr, b32, P, hd_colour, ln);
+    static_assert(fwd_stage<N, SAVE>(9 * HS + 2 + WS).ks == 0 && fwd_stage<N, SAVE>(9 * HS + 1 + WS).ks == N::WKS, "stage table out of step");
 
     // outputs.  Lane half 0 holds rows 0..3 of a head tile, half 1 rows 4..7.
     const float* sc = cst + N::C_SC;
@@ -539,7 +559,8 @@ __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[K
     constexpr int KS = KS_M + KS_E;
     const int lane = pipe.lane;
 #define NERF_BS(i) bwd_stage<N>(i)
-    static_assert(NERF_BS(STAGE0).ks == KS && NERF_BS(STAGE0 + NT - 1).ks == KS && NERF_BS(STAGE0).xloads == NW_NEXT,
+    constexpr int NS = stage_count(NT);
+    static_assert(NERF_BS(STAGE0).ks == KS * (NT < kTPS ? NT : kTPS) && NERF_BS(STAGE0).xloads == NW_NEXT,
                   "stage table out of step");
     auto finish = [&](auto ntc, const f32x16& acc) __attribute__((always_inline)) {
         constexpr int nt = decltype(ntc)::value;
@@ -552,24 +573,28 @@ __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[K
         emit_tfrag(tdy, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
     };
     f32x16 prev;
-    static_for<0, NT>([&](auto ntc) __attribute__((always_inline)) {
-        constexpr int nt = decltype(ntc)::value;
-        pipe.template prefetch<NERF_BS(STAGE0 + nt + kRing - 1).ks>();
-        if (nt == 0) {
+    static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int st = decltype(sc)::value;
+        constexpr int T0 = st * kTPS, TN = (NT - T0) < kTPS ? (NT - T0) : kTPS;
+        pipe.template prefetch<NERF_BS(STAGE0 + st + kRing - 1).ks>();
+        if (st == 0) {
 #pragma unroll
             for (int i = 0; i < NW_NEXT; ++i) nextw[i] = next_mask[(b32 * NW_NEXT + i) * 64 + lane];
         }
-        f32x16 acc;
+        static_for<0, TN>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value, nt = T0 + j;
+            f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        pipe.template tile<KS>(acc, [&](auto kc) __attribute__((always_inline)) {
-            constexpr int ks = decltype(kc)::value;
-            if constexpr (ks < KS_M) return gm[ks];
-            else return ge[ks - KS_M];
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            pipe.template tile<KS, j * KS>(acc, [&](auto kc) __attribute__((always_inline)) {
+                constexpr int ks = decltype(kc)::value;
+                if constexpr (ks < KS_M) return gm[ks];
+                else return ge[ks - KS_M];
+            });
+            if constexpr (nt > 0) finish(IC<nt - 1>{}, prev);          // runs under this tile's MFMAs
+            prev = acc;
         });
-        if constexpr (nt > 0) finish(IC<nt - 1>{}, prev);          // runs under this tile's MFMAs
-        prev = acc;
-        pipe.template arrive<bwd_younger<N>(STAGE0 + nt)>();
+        pipe.template arrive<bwd_younger<N>(STAGE0 + st)>();
     });
     finish(IC<NT - 1>{}, prev);
 #undef NERF_BS
@@ -592,6 +617,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
     make_perm(P, lane);
     constexpr int HKS = N::HKS, HT = N::HT, WKS = N::WKS, WT = N::WT;
     constexpr int HW = (HT + 1) / 2, WW = (WT + 1) / 2;       // sign words per lane per layer
+    constexpr int HS = stage_count(HT), WS = stage_count(WT);
 
     // gradient w.r.t. the pre-sigmoid head outputs and the raw density, as one-k-step B operands:
     // rows 0..3 of a head tile are elements 0..3 of lane half 0, row 4 is element 0 of lane half 1.
@@ -614,7 +640,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
 
     WeightPipe pipe;
     pipe.src = pipe.base = (const char*)a.wbwd;
-    pipe.slot_bytes = N::BWD_SLOT_KS * 1024;
+    pipe.slot_bytes = kTPS * N::BWD_SLOT_KS * 1024;
     pipe.ring = (LDS_AS char*)smem;
     pipe.wave = wave;
     pipe.lane = lane;
@@ -624,39 +650,40 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
     // heads^T: dX9 = Wh^T dz, masked by X9 > 0 -> dY9
     bwd_layer<N, 0, WT, 1, 0, true, 0>(pipe, dzv, none, gw, kw9, nullptr, nokw, a.tdy[9], b32, P);
     // rgb_net1^T (rows of X8 only): dY8 = W9[:, :H]^T dY9   (rgb_net0 has no activation)
-    bwd_layer<N, WT, HT, WKS, 0, false, HW>(pipe, gw, none, ga, nokw, a.mask[7], kwa, a.tdy[8], b32, P);
+    bwd_layer<N, WS, HT, WKS, 0, false, HW>(pipe, gw, none, ga, nokw, a.mask[7], kwa, a.tdy[8], b32, P);
     // [rgb_net0 ; density head]^T: dX7 = W8^T dY8 + wd^T dd, masked by X7 > 0 -> dY7
-    bwd_layer<N, WT + 1 * HT, HT, HKS, 1, true, HW>(pipe, ga, ddv, gb, kwa, a.mask[6], kwb, a.tdy[7], b32, P);
-    bwd_layer<N, WT + 2 * HT, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[5], kwa, a.tdy[6], b32, P);
-    bwd_layer<N, WT + 3 * HT, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[4], kwb, a.tdy[5], b32, P);
-    bwd_layer<N, WT + 4 * HT, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[3], kwa, a.tdy[4], b32, P);
+    bwd_layer<N, WS + 1 * HS, HT, HKS, 1, true, HW>(pipe, ga, ddv, gb, kwa, a.mask[6], kwb, a.tdy[7], b32, P);
+    bwd_layer<N, WS + 2 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[5], kwa, a.tdy[6], b32, P);
+    bwd_layer<N, WS + 3 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[4], kwb, a.tdy[5], b32, P);
+    bwd_layer<N, WS + 4 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[3], kwa, a.tdy[4], b32, P);
     // density_net1.0^T (rows of X3 only; the encoding needs no gradient)
-    bwd_layer<N, WT + 5 * HT, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[2], kwb, a.tdy[3], b32, P);
-    bwd_layer<N, WT + 6 * HT, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[1], kwa, a.tdy[2], b32, P);
-    bwd_layer<N, WT + 7 * HT, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[0], kwb, a.tdy[1], b32, P);
-    bwd_layer<N, WT + 8 * HT, HT, HKS, 0, true, 0>(pipe, gb, none, ga, kwb, nullptr, nokw, a.tdy[0], b32, P);
-    static_assert(bwd_stage<N>(WT + 9 * HT).ks == 0, "stage table out of step");
+    bwd_layer<N, WS + 5 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[2], kwb, a.tdy[3], b32, P);
+    bwd_layer<N, WS + 6 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[1], kwa, a.tdy[2], b32, P);
+    bwd_layer<N, WS + 7 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[0], kwb, a.tdy[1], b32, P);
+    bwd_layer<N, WS + 8 * HS, HT, HKS, 0, true, 0>(pipe, gb, none, ga, kwb, nullptr, nokw, a.tdy[0], b32, P);
+    static_assert(bwd_stage<N>(WS + 9 * HS).ks == 0 && bwd_stage<N>(WS + 9 * HS - 1).ks != 0, "stage table out of step");
 }
 
 // ------------------------------------------------------------------------------------------------
 // Weight gradient: G[n][col0 + k] += sum_m dY[m][n] X[m][k], gb[n] += sum_m dY[m][n], both operands
 // given as T-frags, i.e. already in MFMA operand order for a reduction over samples.  Pure streaming
-// GEMM, HBM-bound (every operand byte feeds 2*256 FLOP): a workgroup of 4 waves owns the whole
+// GEMM, HBM-bound (every operand byte feeds 2*256 FLOP): a workgroup of 4 (or 8) waves owns the whole
 // [NT x KT]-tile output in registers and takes every grid-th 16-sample k-step; each k-step's
 // NT + KT pieces go HBM -> LDS by global_load_lds into a ring of `depth` slots, depth-2 k-steps in
 // flight behind a counted vmcnt, one barrier per k-step.
+struct WgradSeg { const bf16x8* p; int tiles, n_true; };    // a T-frag buffer: its tile count, its true feature count
+struct WgradOut { float* G; int ld, col0; };                // where the (dY segment, X segment) block goes; G NULL = skip
 struct WgradArgs {
-    const bf16x8* a;           // dY T-frags  [nq][NT][64]
-    const bf16x8* b;           // X  T-frags  [nq][KT][64]
+    WgradSeg A[2], B[2];       // dY side (output rows) and X side (output columns): up to two buffers each,
+                               // concatenated along the feature axis (second may have 0 tiles)
+    WgradOut out[2][2];
+    float* gb[2];              // bias gradient per dY segment, or NULL
     int64_t nq;                // 16-sample k-steps
-    int NT, KT, WN, WK;
+    int NT, KT, WN, WK;        // total tiles per side; waves split the output WN x WK
     int depth;                 // ring slots: depth - 2 k-steps stay in flight
-    float* G;                  // fp32 [n_true][ld]
-    int ld, col0, n_true, k_true;
-    float* gb;                 // fp32 [n_true] or NULL
 };
 
-constexpr int kWgradLds = 156 * 1024;      // ring + 4 KiB landing zone for padding loads
+constexpr int kWgradLds = 156 * 1024;      // ring + landing zone for padding loads
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n in 0..63 (the instruction takes an immediate)
 __device__ __forceinline__ void wait_vmcnt(int n) {
@@ -673,15 +700,15 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 #undef NERF_W1
 }
 
-template <int NTW, int KTW>
-__global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(WgradArgs a) {
+template <int NW, int NTW, int KTW>        // NW waves (4 or 8), each owning NTW x KTW output tiles
+__global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave / a.WK, wk = wave % a.WK;
     const int P = a.NT + a.KT;                         // pieces per k-step
-    const int G = (P + 3) >> 2;                        // loads per wave per k-step (1..4), same for every wave
+    const int G = (P + NW - 1) / NW;                   // loads per wave per k-step (1..5), same for every wave
     const unsigned slot_bytes = P * 1024;
     LDS_AS char* ring = (LDS_AS char*)smem;
     const int depth = a.depth;
@@ -701,24 +728,40 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
-    const bool do_bias = a.gb != nullptr && wk == 0;
+    const bool do_bias = (a.gb[0] != nullptr || a.gb[1] != nullptr) && wk == 0;
 
-    // every wave issues exactly G loads per k-step, real pieces first, padding into the scratch KiB
+    // every wave issues exactly G loads per k-step: load g moves piece 4g + wave (a tile of one of the operand
+    // buffers) or, beyond the last piece, padding into the scratch KiB.  Per-load source description is fixed
+    // for the whole sweep and kept in scalar registers: piece address = base + k-step * stride.
+    const char* ld_base[5];
+    int64_t ld_stride[5];
+    unsigned ld_dst[5];
+    bool ld_real[5];
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+        const int p = g * NW + wave;
+        ld_real[g] = g < G && p < P;
+        const bool xside = p >= a.NT;
+        const int t = xside ? p - a.NT : p;
+        const WgradSeg s0 = xside ? a.B[0] : a.A[0], s1 = xside ? a.B[1] : a.A[1];
+        const bool second = t >= s0.tiles;
+        const WgradSeg sg = second ? s1 : s0;
+        ld_base[g] = ld_real[g] ? (const char*)(sg.p + (int64_t)(second ? t - s0.tiles : t) * 64) : (const char*)a.A[0].p;
+        ld_stride[g] = ld_real[g] ? (int64_t)sg.tiles * 1024 : 0;
+        ld_dst[g] = p * 1024;
+    }
     int fill = 0, drain = 0;                           // ring positions of the next k-step to load / to consume
     auto issue = [&](int64_t i) {
         const int64_t q = q0 + i * qstride;
         LDS_AS char* slot = ring + (unsigned)fill * slot_bytes;
         fill = fill + 1 == depth ? 0 : fill + 1;
+        const bool live = i < n;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < 5; ++g) {
             if (g < G) {
-                const int p = g * 4 + wave;
-                const char* src = (const char*)a.a;
-                LDS_AS char* dst = scratch + wave * 1024;
-                if (i < n && p < P) {
-                    src = p < a.NT ? (const char*)(a.a + tfrag_piece(q, a.NT, p) * 64) : (const char*)(a.b + tfrag_piece(q, a.KT, p - a.NT) * 64);
-                    dst = slot + p * 1024;
-                }
+                const bool real = live && ld_real[g];
+                const char* src = real ? ld_base[g] + q * ld_stride[g] : (const char*)a.A[0].p;
+                LDS_AS char* dst = real ? slot + ld_dst[g] : scratch + wave * 1024;
                 __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + lane * 16), (LDS_AS void*)dst, 16, 0, 0);
             }
         }
@@ -766,21 +809,24 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(WgradArgs a) {
     for (int i = 0; i < NTW; ++i) {
         const int nt = wn * NTW + i;
         if (nt >= a.NT) continue;
+        const int sa = nt >= a.A[0].tiles, lt = sa ? nt - a.A[0].tiles : nt;
 #pragma unroll
         for (int j = 0; j < KTW; ++j) {
             const int kt = wk * KTW + j;
             if (kt >= a.KT) continue;
-            const int k = kt * 32 + c;
-            if (k >= a.k_true) continue;
+            const int sb = kt >= a.B[0].tiles, lk = sb ? kt - a.B[0].tiles : kt;
+            const WgradOut o = a.out[sa][sb];
+            const int k = lk * 32 + c;
+            if (o.G == nullptr || k >= a.B[sb].n_true) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int nn = nt * 32 + acc_row(r, h);
-                if (nn < a.n_true) atomicAdd(&a.G[(int64_t)nn * a.ld + a.col0 + k], acc[i][j][r]);
+                const int nn = lt * 32 + acc_row(r, h);
+                if (nn < a.A[sa].n_true) atomicAdd(&o.G[(int64_t)nn * o.ld + o.col0 + k], acc[i][j][r]);
             }
         }
-        if (do_bias) {
-            const int nn = nt * 32 + c;
-            if (nn < a.n_true) atomicAdd(&a.gb[nn], accb[i]);
+        if (do_bias && a.gb[sa] != nullptr) {
+            const int nn = lt * 32 + c;
+            if (nn < a.A[sa].n_true) atomicAdd(&a.gb[sa][nn], accb[i]);
         }
     }
 }
@@ -1179,42 +1225,85 @@ extern "C" int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, int64_t
     return NERF_ERR_SIZE;
 }
 
-template <int NTW, int KTW>
-static int launch_wgrad(const WgradArgs& a, unsigned grid, size_t lds, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)mlp_wgrad_kernel<NTW, KTW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kWgradLds) != hipSuccess)
-            return NERF_ERR_LAUNCH;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((mlp_wgrad_kernel<NTW, KTW>), dim3(grid), dim3(256), lds, st, a);
-    return nerf_launch_status();
-}
-
 // Split the NT x KT output tiles over the 4 waves (WN x WK) so that the per-wave block fits an instantiated
 // template (tn x tk accumulator tiles) with the fewest tiles.
-static bool wgrad_config(int NT, int KT, int* WN, int* WK, int* tn, int* tk) {
-    static const int kSplit[3][2] = {{2, 2}, {4, 1}, {1, 4}};
-    static const int kTmpl[6][2] = {{1, 1}, {1, 2}, {1, 4}, {2, 2}, {2, 4}, {4, 4}};
+static bool wgrad_config(int NT, int KT, int* NW, int* WN, int* WK, int* tn, int* tk) {
+    // {waves, WN, WK} splits and {waves, tn, tk} instantiations; 8 waves (half the registers each) take the
+    // outputs too large for 16 accumulator tiles per wave
+    static const int kSplit[5][3] = {{4, 2, 2}, {4, 4, 1}, {4, 1, 4}, {8, 2, 4}, {8, 4, 2}};
+    static const int kTmpl[9][3] = {{4, 1, 1}, {4, 1, 2}, {4, 1, 4}, {4, 2, 2}, {4, 2, 4}, {4, 2, 5}, {4, 4, 4},
+                                    {8, 4, 3}, {8, 5, 2}};
     int best = 1 << 30;
     *tn = *tk = 0;
     for (const auto& sp : kSplit) {
-        const int ntw = (NT + sp[0] - 1) / sp[0], ktw = (KT + sp[1] - 1) / sp[1];
+        const int ntw = (NT + sp[1] - 1) / sp[1], ktw = (KT + sp[2] - 1) / sp[2];
         for (const auto& t : kTmpl)
-            if (t[0] >= ntw && t[1] >= ktw && t[0] * t[1] < best) {
-                best = t[0] * t[1]; *tn = t[0]; *tk = t[1]; *WN = sp[0]; *WK = sp[1];
+            if (t[0] == sp[0] && t[1] >= ntw && t[2] >= ktw && t[0] * t[1] * t[2] < best) {
+                best = t[0] * t[1] * t[2]; *NW = sp[0]; *tn = t[1]; *tk = t[2]; *WN = sp[1]; *WK = sp[2];
             }
     }
     return *tn != 0;
 }
 
-// Which mlp_wgrad_kernel<tn, tk> instantiation nerf_mlp_wgrad launches for these feature counts (profilers
-// label launches with it).
-extern "C" int nerf_mlp_wgrad_config(int n_feat, int k_feat, int* tn, int* tk) {
+// Which mlp_wgrad_kernel<nw, tn, tk> instantiation a launch with these total padded feature counts uses
+// (profilers label launches with it).
+extern "C" int nerf_mlp_wgrad_config(int n_feat, int k_feat, int* nw, int* tn, int* tk) {
     int wn, wk;
-    NERF_REQUIRE(tn && tk && n_feat > 0 && k_feat > 0 && n_feat % 32 == 0 && k_feat % 32 == 0);
-    return wgrad_config(n_feat / 32, k_feat / 32, &wn, &wk, tn, tk) ? NERF_OK : NERF_ERR_SIZE;
+    NERF_REQUIRE(nw && tn && tk && n_feat > 0 && k_feat > 0 && n_feat % 32 == 0 && k_feat % 32 == 0);
+    return wgrad_config(n_feat / 32, k_feat / 32, nw, &wn, &wk, tn, tk) ? NERF_OK : NERF_ERR_SIZE;
+}
+
+template <int NW, int NTW, int KTW>
+static int launch_wgrad(const WgradArgs& a, unsigned grid, size_t lds, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)mlp_wgrad_kernel<NW, NTW, KTW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kWgradLds) != hipSuccess)
+            return NERF_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mlp_wgrad_kernel<NW, NTW, KTW>), dim3(grid), dim3(64 * NW), lds, st, a);
+    return nerf_launch_status();
+}
+
+// dW blocks for up to two dY buffers x two X buffers in one pass over the samples (each operand byte read once).
+extern "C" int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint, void* stream) {
+    if (n_samples == 0) return NERF_OK;
+    NERF_REQUIRE(d && n_samples > 0);
+    WgradArgs a;
+    a.NT = a.KT = 0;
+    for (int i = 0; i < 2; ++i) {
+        const int nf = d->dy_feat[i], kf = d->x_feat[i];
+        NERF_REQUIRE(nf >= 0 && kf >= 0 && nf % 32 == 0 && kf % 32 == 0 && (i == 1 || (nf > 0 && kf > 0)));
+        NERF_REQUIRE((nf == 0 || d->dy[i]) && (kf == 0 || d->x[i]) && d->dy_true[i] <= nf && d->x_true[i] <= kf);
+        a.A[i] = {(const bf16x8*)d->dy[i], nf / 32, d->dy_true[i]};
+        a.B[i] = {(const bf16x8*)d->x[i], kf / 32, d->x_true[i]};
+        a.gb[i] = nf ? d->gb[i] : nullptr;
+        a.NT += nf / 32;
+        a.KT += kf / 32;
+        for (int j = 0; j < 2; ++j) a.out[i][j] = {d->G[i][j], d->ld[i][j], d->col0[i][j]};
+    }
+    NERF_REQUIRE(a.out[0][0].G != nullptr);
+    a.nq = ((n_samples + 255) / 256) * 16;            // 16-sample k-steps, whole 256-sample workgroup tiles
+    int nw = 0, tn = 0, tk = 0;
+    if (!wgrad_config(a.NT, a.KT, &nw, &a.WN, &a.WK, &tn, &tk)) return NERF_ERR_SIZE;
+    unsigned grid = grid_hint > 0 ? (unsigned)grid_hint : 256u;
+    if ((int64_t)grid > a.nq) grid = (unsigned)a.nq;
+    // as deep a ring as the LDS and the 6-bit vmcnt allow; nw KiB of landing zone for padding loads
+    const int pieces = a.NT + a.KT, loads = (pieces + nw - 1) / nw;
+    if (loads > 5) return NERF_ERR_SIZE;
+    a.depth = (kWgradLds / 1024 - nw) / pieces;
+    if ((a.depth - 2) * loads > 63) a.depth = 63 / loads + 2;
+    const size_t lds = (size_t)(a.depth * pieces + nw) * 1024;
+    hipStream_t st = nerf_stream(stream);
+    if (nw == 8) return tn == 4 ? launch_wgrad<8, 4, 3>(a, grid, lds, st) : launch_wgrad<8, 5, 2>(a, grid, lds, st);
+    if (tn == 1 && tk == 1) return launch_wgrad<4, 1, 1>(a, grid, lds, st);
+    if (tn == 1 && tk == 2) return launch_wgrad<4, 1, 2>(a, grid, lds, st);
+    if (tn == 1 && tk == 4) return launch_wgrad<4, 1, 4>(a, grid, lds, st);
+    if (tn == 2 && tk == 2) return launch_wgrad<4, 2, 2>(a, grid, lds, st);
+    if (tn == 2 && tk == 4) return launch_wgrad<4, 2, 4>(a, grid, lds, st);
+    if (tn == 2 && tk == 5) return launch_wgrad<4, 2, 5>(a, grid, lds, st);
+    return launch_wgrad<4, 4, 4>(a, grid, lds, st);
 }
 
 // G[n_true, ld] (+= at column col0, k_true columns) and gb[n_true] (nullable) accumulate dY^T X over
@@ -1223,29 +1312,11 @@ extern "C" int nerf_mlp_wgrad(const void* dy_tfrag, int n_feat, const void* x_tf
                               float* G, int ld, int col0, int n_true, int k_true, float* gb, int grid_hint,
                               void* stream) {
     if (n_samples == 0) return NERF_OK;
-    NERF_REQUIRE(dy_tfrag && x_tfrag && G && n_samples > 0 && n_feat > 0 && k_feat > 0 && n_feat % 32 == 0 &&
-                 k_feat % 32 == 0 && n_feat <= 256 && k_feat <= 256 && n_true <= n_feat && k_true <= k_feat);
-    WgradArgs a;
-    a.a = (const bf16x8*)dy_tfrag;
-    a.b = (const bf16x8*)x_tfrag;
-    a.nq = ((n_samples + 255) / 256) * 16;            // 16-sample k-steps, whole 256-sample workgroup tiles
-    a.NT = n_feat / 32;
-    a.KT = k_feat / 32;
-    int tn = 0, tk = 0;
-    if (!wgrad_config(a.NT, a.KT, &a.WN, &a.WK, &tn, &tk)) return NERF_ERR_SIZE;
-    a.G = G; a.ld = ld; a.col0 = col0; a.n_true = n_true; a.k_true = k_true; a.gb = gb;
-    unsigned grid = grid_hint > 0 ? (unsigned)grid_hint : 256u;
-    if ((int64_t)grid > a.nq) grid = (unsigned)a.nq;
-    // as deep a ring as the LDS and the 6-bit vmcnt allow
-    const int pieces = a.NT + a.KT, loads = (pieces + 3) / 4;
-    a.depth = (kWgradLds / 1024 - 4) / pieces;
-    if ((a.depth - 2) * loads > 63) a.depth = 63 / loads + 2;
-    const size_t lds = (size_t)(a.depth * pieces + 4) * 1024;
-    hipStream_t st = nerf_stream(stream);
-    if (tn == 1 && tk == 1) return launch_wgrad<1, 1>(a, grid, lds, st);
-    if (tn == 1 && tk == 2) return launch_wgrad<1, 2>(a, grid, lds, st);
-    if (tn == 1 && tk == 4) return launch_wgrad<1, 4>(a, grid, lds, st);
-    if (tn == 2 && tk == 2) return launch_wgrad<2, 2>(a, grid, lds, st);
-    if (tn == 2 && tk == 4) return launch_wgrad<2, 4>(a, grid, lds, st);
-    return launch_wgrad<4, 4>(a, grid, lds, st);
+    NERF_REQUIRE(dy_tfrag && x_tfrag && G && n_feat <= 256 && k_feat <= 256);
+    nerf_wgrad_desc d = {};
+    d.dy[0] = dy_tfrag; d.dy_feat[0] = n_feat; d.dy_true[0] = n_true;
+    d.x[0] = x_tfrag; d.x_feat[0] = k_feat; d.x_true[0] = k_true;
+    d.G[0][0] = G; d.ld[0][0] = ld; d.col0[0][0] = col0;
+    d.gb[0] = gb;
+    return nerf_mlp_wgrad_multi(&d, n_samples, grid_hint, stream);
 }

@@ -21,7 +21,15 @@ _lib.register('nerf_mlp_fwd', c_int, [POINTER(MlpDims), _P, _P, _P, _P, c_int64,
 
 _lib.register('nerf_mlp_bwd', c_int, [POINTER(MlpDims), _P, c_int64, _P, _P, _P, _P, _P, _P, POINTER(c_void_p),
                                       POINTER(c_void_p), _P])
-_lib.register('nerf_mlp_wgrad_config', c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)])
+class WgradDesc(ctypes.Structure):
+    """nerf_wgrad_desc of include/nerf_amd.h."""
+    _fields_ = [('dy', c_void_p * 2), ('dy_feat', c_int * 2), ('dy_true', c_int * 2),
+                ('x', c_void_p * 2), ('x_feat', c_int * 2), ('x_true', c_int * 2),
+                ('G', (c_void_p * 2) * 2), ('ld', (c_int * 2) * 2), ('col0', (c_int * 2) * 2), ('gb', c_void_p * 2)]
+
+
+_lib.register('nerf_mlp_wgrad_multi', c_int, [POINTER(WgradDesc), c_int64, c_int, _P])
+_lib.register('nerf_mlp_wgrad_config', c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)])
 _lib.register('nerf_mlp_wgrad', c_int, [_P, c_int, _P, c_int, c_int64, _P, c_int, c_int, c_int, c_int, _P, c_int, _P])
 
 STREAMED = (['density_net0.%d' % i for i in (0, 2, 4, 6)] + ['density_net1.%d' % i for i in (0, 2, 4, 6)]
@@ -102,24 +110,31 @@ class Packed:
         self.wgrad_flops = 2.0 * macs_fwd
         self.DT, self.VT = (self.DKS + 1) // 2, (self.VKS + 1) // 2
         # bf16 operand bytes per sample that the weight-gradient launches read (see _wgrad_plan)
-        self.wgrad_bytes = 2.0 * sum(nf + kf for _, nf, _, kf, *_ in _wgrad_plan(self))
+        self.wgrad_bytes = 2.0 * sum(sum(s[1] for s in dys) + sum(s[1] for s in xs) for dys, xs, _ in _wgrad_plan(self))
 
 
 def _wgrad_plan(pk):
-    """The weight-gradient launches of one backward pass:
-    (dY index, dY features, X source, X features, parameter, column offset, true rows, true cols, with bias).
-    X sources: ('x', i) saved activation i, 'enc', 'view'.  dY 10 / 11 are the colour / density head tiles."""
+    """The weight-gradient launches of one backward pass.  Each launch: (dY segments, X segments, blocks) with
+    a dY segment = (dY index, padded features, true features, parameter owning the bias or None),
+    an X segment = (source, padded features, true features), and blocks[i][j] = (parameter, column offset) or None.
+    X sources: ('x', i) saved activation i, 'enc', 'view'.  dY 10 / 11 are the colour / density head tiles.
+    Buffers shared by two gradients ride in one launch, so every operand is read once per pass."""
     H, W, D, V = pk.H, pk.W, pk.D, pk.V
     HP, WP, DP, VP = 32 * pk.HT, 32 * pk.WT, 32 * pk.DT, 32 * pk.VT
-    plan = [(0, HP, 'enc', DP, 'density_net0.0', 0, H, D, True)]
-    plan += [(l, HP, ('x', l - 1), HP, 'density_net0.%d' % i, 0, H, H, True) for l, i in ((1, 2), (2, 4), (3, 6))]
-    plan += [(4, HP, ('x', 3), HP, 'density_net1.0', 0, H, H, True), (4, HP, 'enc', DP, 'density_net1.0', H, H, D, False)]
-    plan += [(l, HP, ('x', l - 1), HP, 'density_net1.%d' % i, 0, H, H, True) for l, i in ((5, 2), (6, 4), (7, 6))]
-    plan += [(11, 32, ('x', 7), HP, 'final_density.0', 0, 1, H, True),
-             (8, HP, ('x', 7), HP, 'rgb_net0.0', 0, H, H, True),
-             (9, WP, ('x', 8), HP, 'rgb_net1.0', 0, W, H, True),
-             (9, WP, 'view', VP, 'rgb_net1.0', H, W, V, False),
-             (10, 32, ('x', 9), WP, 'final_rgb.0', 0, 3, W, True)]
+    one = lambda di, nf, nt, name, xs, kf, kt: ([(di, nf, nt, name)], [(xs, kf, kt)], [[(name, 0)]])
+    plan = [one(0, HP, H, 'density_net0.0', 'enc', DP, D)]
+    plan += [one(l, HP, H, 'density_net0.%d' % i, ('x', l - 1), HP, H) for l, i in ((1, 2), (2, 4), (3, 6))]
+    # density_net1.0 takes [X3 | encoding]
+    plan += [([(4, HP, H, 'density_net1.0')], [(('x', 3), HP, H), ('enc', DP, D)],
+              [[('density_net1.0', 0), ('density_net1.0', H)]])]
+    plan += [one(l, HP, H, 'density_net1.%d' % i, ('x', l - 1), HP, H) for l, i in ((5, 2), (6, 4), (7, 6))]
+    # rgb_net0 and the density head both read the trunk output X7
+    plan += [([(8, HP, H, 'rgb_net0.0'), (11, 32, 1, 'final_density.0')], [(('x', 7), HP, H)],
+              [[('rgb_net0.0', 0)], [('final_density.0', 0)]])]
+    # rgb_net1.0 takes [X8 | view features]
+    plan += [([(9, WP, W, 'rgb_net1.0')], [(('x', 8), HP, H), ('view', VP, V)],
+              [[('rgb_net1.0', 0), ('rgb_net1.0', H)]])]
+    plan += [one(10, 32, 3, 'final_rgb.0', ('x', 9), WP, W)]
     return plan
 
 
@@ -203,14 +218,14 @@ def wgrad_kernel_name(n_feat, k_feat):
     """Symbol of the kernel instantiation that handles these feature counts."""
     key = (n_feat, k_feat)
     if key not in _WGRAD_KERNEL:
-        tn, tk = c_int(), c_int()
-        check(lib().nerf_mlp_wgrad_config(n_feat, k_feat, ctypes.byref(tn), ctypes.byref(tk)))
-        _WGRAD_KERNEL[key] = 'mlp_wgrad_kernel<%d, %d>' % (tn.value, tk.value)
+        nw, tn, tk = c_int(), c_int(), c_int()
+        check(lib().nerf_mlp_wgrad_config(n_feat, k_feat, ctypes.byref(nw), ctypes.byref(tn), ctypes.byref(tk)))
+        _WGRAD_KERNEL[key] = 'mlp_wgrad_kernel<%d, %d, %d>' % (nw.value, tn.value, tk.value)
     return _WGRAD_KERNEL[key]
 
 
 def _wgrad(dy, n_feat, x, k_feat, n_samples, G, col0, n_true, k_true, gb):
-    # algorithmic work of the launch: every operand byte once, 2 FLOP per true multiply-add
+    """Single-block launch (dW[:, col0:col0+k_true] += dY^T X)."""
     with profiling.timed(wgrad_kernel_name(n_feat, k_feat), flops=2.0 * n_true * k_true * n_samples,
                          bytes_=2.0 * (n_feat + k_feat) * n_samples):
         check(lib().nerf_mlp_wgrad(_raw(dy), n_feat, _raw(x), k_feat, n_samples, ptr(G), G.stride(0), col0, n_true,
@@ -219,10 +234,25 @@ def _wgrad(dy, n_feat, x, k_feat, n_samples, G, col0, n_true, k_true, gb):
 
 def mlp_weight_grads(pk, acts, dys, n_samples, grads):
     """Accumulate all weight / bias gradients into `grads` (name -> zero-initialised or running fp32 tensor)."""
-    for di, nf, xs, kf, name, col0, n_true, k_true, with_bias in _wgrad_plan(pk):
-        x = acts[20] if xs == 'enc' else acts[21] if xs == 'view' else acts[xs[1]]
-        _wgrad(dys[di], nf, x, kf, n_samples, grads[name + '.weight'], col0, n_true, k_true,
-               grads[name + '.bias'] if with_bias else None)
+    for dsegs, xsegs, blocks in _wgrad_plan(pk):
+        d = WgradDesc()
+        flops = 0.0
+        for i, (di, nf, nt, name) in enumerate(dsegs):
+            d.dy[i], d.dy_feat[i], d.dy_true[i] = dys[di].data_ptr(), nf, nt
+            d.gb[i] = grads[name + '.bias'].data_ptr()
+        for j, (xs, kf, kt) in enumerate(xsegs):
+            x = acts[20] if xs == 'enc' else acts[21] if xs == 'view' else acts[xs[1]]
+            d.x[j], d.x_feat[j], d.x_true[j] = x.data_ptr(), kf, kt
+        for i, row in enumerate(blocks):
+            for j, blk in enumerate(row):
+                if blk is not None:
+                    w = grads[blk[0] + '.weight']
+                    d.G[i][j], d.ld[i][j], d.col0[i][j] = w.data_ptr(), w.stride(0), blk[1]
+                    flops += 2.0 * dsegs[i][2] * xsegs[j][2] * n_samples
+        nf_all, kf_all = sum(s[1] for s in dsegs), sum(s[1] for s in xsegs)
+        # algorithmic work of the launch: every operand byte once, 2 FLOP per true multiply-add
+        with profiling.timed(wgrad_kernel_name(nf_all, kf_all), flops=flops, bytes_=2.0 * (nf_all + kf_all) * n_samples):
+            check(lib().nerf_mlp_wgrad_multi(ctypes.byref(d), n_samples, 0, stream()))
 
 
 PARAM_NAMES = [n + s for n in STREAMED + ['final_density.0', 'final_rgb.0'] for s in ('.weight', '.bias')]
