@@ -65,6 +65,13 @@ int nerf_pe_encode(const float* x, int64_t n_points, int min_deg, int max_deg, i
 int nerf_sar_raygen(const float* az, const float* el, int64_t n_rays, float* ray_d, float* ray_p,
                     void* stream);
 
+/* Pinhole-camera rays for ray ids (flat (camera, row, col) index; ids NULL = 0..n-1): origins, directions,
+ * viewdirs [n,3], radii, lossmult (= 1), near, far [n].  cam_to_world is [n_cams, 3, 4] row-major fp32.  Ids are
+ * not range-checked against n_cams * h * w: the caller draws them.     reference: dataloader.py:103-138 */
+int nerf_pinhole_rays(const float* cam_to_world, int n_cams, int h, int w, float focal, float near_, float far_,
+                      const int64_t* ids, int64_t n, float* origins, float* directions, float* viewdirs,
+                      float* radii, float* lossmult, float* near_out, float* far_out, void* stream);
+
 /* ---- (c) hierarchical resampling ------------------------------------------------------ */
 
 /* new_t[N,n_out] = inverse-CDF samples of the blurred, padded weights:

@@ -310,6 +310,67 @@ extern "C" int nerf_pe_encode(const float* x, int64_t n_points, int min_deg, int
     return nerf_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pinhole camera rays on the device (dataloader.py:103-138): ray id -> (camera, row, col) -> origin, direction,
+// unit view direction, radius from the distance to the next row's direction, lossmult = 1, near, far.
+// Arithmetic follows the NumPy expression order in fp32 (no contraction in this file); the radius is
+// dx * 2 / sqrt(12) with the division in double, as NumPy 2 evaluates a float32 array over np.sqrt(12).
+__device__ __forceinline__ void pinhole_dir(const float* __restrict__ R /* 3x4 row-major */, float x, float y, int h,
+                                            int w, float focal, float (&d)[3]) {
+    const float c0 = ((x - (float)(w * 0.5)) + 0.5f) / focal;
+    const float c1 = -(((y - (float)(h * 0.5)) + 0.5f) / focal);
+    const float c2 = -1.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = (c0 * R[i * 4 + 0] + c1 * R[i * 4 + 1]) + c2 * R[i * 4 + 2];
+}
+
+__global__ void pinhole_rays_kernel(const float* __restrict__ c2w, int n_cams, int h, int w, float focal, float near_,
+                                    float far_, const int64_t* __restrict__ ids, int64_t n, float* __restrict__ origins,
+                                    float* __restrict__ directions, float* __restrict__ viewdirs,
+                                    float* __restrict__ radii, float* __restrict__ lossmult, float* __restrict__ near_o,
+                                    float* __restrict__ far_o) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t id = ids ? ids[i] : i;
+    const int col = (int)(id % w);
+    const int row = (int)((id / w) % h);
+    const int64_t cam = id / ((int64_t)w * h);
+    const float* R = c2w + cam * 12;
+    float d[3], e[3];
+    pinhole_dir(R, (float)col, (float)row, h, w, focal, d);
+    // neighbour along the row axis; the last row reuses the spacing of rows h-3 / h-2: upstream appends
+    // dx[:, -2:-1] of the (h-1)-row difference array (dataloader.py:122-123)
+    const int r0 = row < h - 1 ? row : h - 3;
+    float a[3];
+    pinhole_dir(R, (float)col, (float)r0, h, w, focal, a);
+    pinhole_dir(R, (float)col, (float)(r0 + 1), h, w, focal, e);
+    const float q0 = a[0] - e[0], q1 = a[1] - e[1], q2 = a[2] - e[2];
+    const float dx = sqrtf((q0 * q0 + q1 * q1) + q2 * q2);
+    const float nrm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        origins[i * 3 + k] = R[k * 4 + 3];
+        directions[i * 3 + k] = d[k];
+        viewdirs[i * 3 + k] = d[k] / nrm;
+    }
+    radii[i] = (float)((double)(dx * 2.0f) / sqrt(12.0));
+    lossmult[i] = 1.0f;
+    near_o[i] = near_;
+    far_o[i] = far_;
+}
+
+extern "C" int nerf_pinhole_rays(const float* cam_to_world, int n_cams, int h, int w, float focal, float near_, float far_,
+                                 const int64_t* ids, int64_t n, float* origins, float* directions, float* viewdirs,
+                                 float* radii, float* lossmult, float* near_out, float* far_out, void* stream) {
+    if (n == 0) return NERF_OK;
+    NERF_REQUIRE(cam_to_world && origins && directions && viewdirs && radii && lossmult && near_out && far_out &&
+                 n > 0 && n_cams > 0 && h >= 3 && w >= 1 && focal > 0.f);
+    hipLaunchKernelGGL(pinhole_rays_kernel, dim3(nerf_blocks(n, 256)), dim3(256), 0, nerf_stream(stream), cam_to_world,
+                       n_cams, h, w, focal, near_, far_, ids, n, origins, directions, viewdirs, radii, lossmult, near_out,
+                       far_out);
+    return nerf_launch_status();
+}
+
 extern "C" int nerf_sar_raygen(const float* az, const float* el, int64_t n_rays, float* ray_d, float* ray_p,
                                void* stream) {
     if (n_rays == 0) return NERF_OK;

@@ -68,6 +68,25 @@ def sar_raygen(az, el):
     return ray_d, ray_p
 
 
+def pinhole_rays(cam_to_world, h, w, focal, near, far, ids=None):
+    """Rays of a pinhole camera model generated on the device (dataloader.py:103-138) -> utils.Rays of `[n, .]`
+    tensors.  cam_to_world: [C, 3 or 4, 4]; ids: flat (camera, row, col) indices (int64) or None for every pixel."""
+    from .utils import Rays
+    c2w = f32c(cam_to_world[:, :3, :4])
+    n_cams = c2w.shape[0]
+    if ids is None:
+        n, idp = n_cams * h * w, None
+    else:
+        ids = ids.to(torch.int64).contiguous()
+        n, idp = ids.numel(), ptr(ids, torch.int64)
+    dev = c2w.device
+    o, d, v = (torch.empty(n, 3, device=dev, dtype=torch.float32) for _ in range(3))
+    r, lm, ne, fa = (torch.empty(n, 1, device=dev, dtype=torch.float32) for _ in range(4))
+    check(lib().nerf_pinhole_rays(ptr(c2w), n_cams, h, w, float(focal), float(near), float(far), idp, n, ptr(o), ptr(d),
+                                  ptr(v), ptr(r), ptr(lm), ptr(ne), ptr(fa), stream()))
+    return Rays(o, d, v, r, lm, ne, fa)
+
+
 def resample(t_vals, weights, n_out, resample_padding, u_rand=None, blur=True, return_idx=False, return_cdf=False):
     t_vals, weights = f32c(t_vals), f32c(weights)
     n, s1 = t_vals.shape

@@ -176,3 +176,16 @@ def test_losses_lr_and_raygen(golden):
     ray_d, ray_p = O.sar_rays(T(fx['az']), T(fx['el']))
     close(ray_d, T(fx['ray_d']))
     close(ray_p, T(fx['ray_p']), 1e-6, 1e-2)
+
+
+def test_pinhole_rays_oracle_properties():
+    """No fixture exists for ray generation (see the oracle's docstring): check what the definition implies."""
+    import numpy as np
+    h, w, focal = 8, 10, 12.0
+    c2w = np.eye(4, dtype=np.float32)[None, :3]
+    o, d, v, r, lm, ne, fa = O.pinhole_rays(c2w, h, w, focal, 2.0, 6.0)
+    assert o.shape == (80, 3) and r.shape == (80, 1) and bool((o == 0).all()) and bool((lm == 1).all())
+    assert torch.allclose(v.norm(dim=-1), torch.ones(80), atol=1e-6)
+    assert torch.allclose(d[:, 2], -torch.ones(80)) and float(d[0, 0]) == (0 - 5.0 + 0.5) / 12.0
+    assert torch.allclose(r, torch.full((80, 1), (1 / 12.0) * 2 / 12 ** 0.5), rtol=1e-6)      # identity pose: dx = 1/focal
+    assert bool((ne == 2).all()) and bool((fa == 6).all())
