@@ -208,11 +208,12 @@ int nerf_view_frag(const float* dirs, int64_t n_rays, int min_deg, int max_deg, 
 /* Forward chain for n_samples rows: raw_density[M], raw_rgb[M,3] (after the sigmoid),
  * raw_angle[M,2] (SAR).  Row m takes the view features of ray m / ray_div (NeRF, ray_div = samples
  * per ray) or m % ray_div (SAR, ray_div = rays per chunk -- the row order upstream produces,
- * model.py:351-354).  acts: NULL for inference, else 22 device pointers that receive what the
+ * model.py:351-354).  acts: NULL for inference, else 22 (SAR: 23) device pointers that receive what the
  * backward pass reads: [0..9] the activations X0..X9 as transposed bf16 fragments (nblk * features
  * * 128 bytes each, nblk = 4 * ceil(M / 256)), [10..19] their ReLU sign words (nblk * 2 *
  * ceil(features / 64) * 256 bytes; [18] unused, may be NULL), [20] / [21] the position encoding and
- * view features as transposed fragments.             reference: model.py:117-132, 343-359 */
+ * view features as transposed fragments, [22] (SAR only) the trunk output in fragment order (nblk * H_padded
+ * * 128 bytes).                                        reference: model.py:117-132, 343-359 */
 int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* consts, const void* enc_frag,
                  const void* view_frag, int64_t n_samples, int ray_div, int64_t n_rays, void* const* acts,
                  float* raw_density, float* raw_rgb, float* raw_angle, float* ln_stats, void* stream);
@@ -222,12 +223,15 @@ int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* const
  * pre-activation) as transposed bf16 fragments (feature on the lane, 16 samples per k-step:
  * [block of 32 samples][2][features/32][64 lanes][8]): dys[0..9] for the ten streamed layers,
  * dys[10] / dys[11] the 32-row head tiles (colour heads / density head).  acts are the 22 buffers
- * nerf_mlp_fwd saved (only the ReLU sign words acts[10..19] are read).  NeRF heads only (SAR trains
- * on the fp32 path).
+ * nerf_mlp_fwd saved (only the ReLU sign words acts[10..19] are read; SAR also acts[22]).  SAR heads
+ * (model.py:278-302): g_angle [M,2], raw_angle, raw_density (the forward's outputs), ln_stats and the forward
+ * constants block are required too; the density head tile then carries rows g*rstd, g*rstd*mean, g, from which
+ * the LayerNorm and density-weight gradients are assembled (NeRF: pass NULL for them).
  *                              reference: autograd of model.py:117-132 (aten::mm, threshold_backward) */
-int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, int64_t n_samples, const float* g_density,
-                 const float* g_rgb, const float* g_angle, const float* raw_rgb, const float* raw_angle,
-                 const float* ln_stats, void* const* acts, void* const* dys, void* stream);
+int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, const float* consts, int64_t n_samples,
+                 const float* g_density, const float* g_rgb, const float* g_angle, const float* raw_density,
+                 const float* raw_rgb, const float* raw_angle, const float* ln_stats, void* const* acts,
+                 void* const* dys, void* stream);
 
 /* Weight / bias gradient of one linear layer from transposed fragments: G[n, col0 + k] += sum_m dY[m,n] X[m,k]
  * (n < n_true, k < k_true; G is fp32 [n_true, ld]) and gb[n] += sum_m dY[m,n] (gb nullable).

@@ -167,6 +167,8 @@ struct MlpFwdArgs {
     unsigned* mask[10];        // ReLU sign words of X0..X7, X9: [b32][ceil(tiles/2)][64] (index 8 unused)
     bf16x8* t_enc;             // position encoding as T-frags, ceil(DKS/2) tiles
     bf16x8* t_view;            // view features as T-frags, ceil(VKS/2) tiles
+    bf16x8* x7_frag;           // SAR training: the trunk output X7 once more in frag order [nblk][HKS][2][64]
+                               // (the LayerNorm backward needs it with the sample on the lane)
     float* raw_density;        // [M]
     float* raw_rgb;            // [M,3]  (post sigmoid)
     float* raw_angle;          // [M,2]  (SAR, post sigmoid)
@@ -197,10 +199,11 @@ constexpr StageDesc fwd_stage(int i) {
     const int tiles[kL] = {N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, 1, N::HT, N::WT, 1};
     const int ks[kL] = {N::DKS, N::HKS, N::HKS, N::HKS, N::HKS + N::DKS, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS,
                         N::HKS + N::VKS, N::WKS};
-    const int kind[kL] = {2, 2, 2, 2, 2, 2, 2, 2, 0, 1, 2, 0};     // 0 head (nothing saved), 1 saved, 2 saved + sign words
+    // 0 head (nothing saved), 1 saved, 2 saved + sign words, 3 as 2 + a frag-order copy (SAR trunk output)
+    const int kind[kL] = {2, 2, 2, 2, 2, 2, 2, N::SAR ? 3 : 2, 0, 1, 2, 0};
     // stores that finishing tile t of layer l issues: 2 T-frag pieces, + the sign word after every second tile
     auto tile_stores = [&](int l, int t) {
-        return (!SAVE || kind[l] == 0) ? 0 : 2 + ((kind[l] == 2 && ((t & 1) || t + 1 == tiles[l])) ? 1 : 0);
+        return (!SAVE || kind[l] == 0) ? 0 : 2 + ((kind[l] >= 2 && ((t & 1) || t + 1 == tiles[l])) ? 1 : 0) + (kind[l] == 3 ? 2 : 0);
     };
     if (i < 0) return {0, 0, 0, 0};
     for (int l = 0; l < kL; ++l) {
@@ -356,7 +359,7 @@ template <class N, bool SAVE, int STAGE0, int NT, int KS_M, int KS_E, bool RELU,
 __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[KM], const bf16x8 (&xe)[KE],
                                           bf16x8 (&out)[KO], const float* bias, int h, bf16x8* tsave,
                                           unsigned* msave, int64_t b32, const bf16x8 (&P)[2], float (&head)[4],
-                                          float (&ln)[2]) {
+                                          float (&ln)[2], bf16x8* fsave = nullptr) {
     constexpr int KS = KS_M + KS_E;
     constexpr bool kMask = SAVE && RELU;
     const int lane = pipe.lane;
@@ -396,6 +399,11 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
             out[2 * nt + s] = o;
         }
         if (SAVE) emit_tfrag(tsave, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
+        if (SAVE && EPI == EPI_TRUNK && N::SAR) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                __builtin_nontemporal_store(out[2 * nt + s], &fsave[(((b32 >> 1) * (2 * NT) + 2 * nt + s) * 2 + (b32 & 1)) * 64 + lane]);
+        }
         if (kMask && ((nt & 1) || nt + 1 == NT)) {
             __builtin_nontemporal_store(signs, &msave[(b32 * ((NT + 1) / 2) + (nt >> 1)) * 64 + lane]);
             signs = 0;
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     fwd_layer<N, SAVE, 4 * HS, HT, HKS, N::DKS, true, EPI_PLAIN>(pipe, xb, enc, xa, bias + 4 * N::HP, h, a.tx[4], a.mask[4], b32, P, hd_density, ln);
     fwd_layer<N, SAVE, 5 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 5 * N::HP, h, a.tx[5], a.mask[5], b32, P, hd_density, ln);
     fwd_layer<N, SAVE, 6 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 6 * N::HP, h, a.tx[6], a.mask[6], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, 7 * HS, HT, HKS, 0, true, EPI_TRUNK>(pipe, xa, none, xb, bias + 7 * N::HP, h, a.tx[7], a.mask[7], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 7 * HS, HT, HKS, 0, true, EPI_TRUNK>(pipe, xa, none, xb, bias + 7 * N::HP, h, a.tx[7], a.mask[7], b32, P, hd_density, ln, a.x7_frag);
     // final_density as one more output tile on X7 (row 0), then rgb_net0 (no activation): X7 -> X8
     fwd_layer<N, SAVE, 8 * HS, 1, HKS, 0, false, EPI_HEAD>(pipe, xb, none, xw, cst + N::C_BIASD, h, nullptr, nullptr, b32, P, hd_density, ln);
     fwd_layer<N, SAVE, 8 * HS + 1, HT, HKS, 0, false, EPI_PLAIN>(pipe, xb, none, xa, bias + 8 * N::HP, h, a.tx[8], nullptr, b32, P, hd_colour, ln);
@@ -541,29 +549,40 @@ struct MlpBwdArgs {
     const float* g_angle;      // [M,2] (SAR)
     const float* raw_rgb;      // [M,3] saved sigmoid outputs
     const float* raw_angle;    // [M,2]
-    const float* ln_stats;     // [M,2] (SAR)
+    const float* ln_stats;     // [M,2] (SAR: mean, rstd of the trunk output)
+    const float* raw_density;  // [M]   (SAR: the forward's density output)
+    const float* consts;       // the forward constants block (SAR: LayerNorm scalars)
+    const bf16x8* x7_frag;     // SAR: trunk output in frag order
     const unsigned* mask[10];  // ReLU sign words of X0..X9 (index 8 unused)
     bf16x8* tdy[10];           // dY0..dY9 as T-frags
     bf16x8* tdy_hd;            // 1-tile T-frag of dL/d(pre-sigmoid colour outputs), rows 0..4
-    bf16x8* tdy_dens;          // 1-tile T-frag of dL/d raw_density (row 0)
+    bf16x8* tdy_dens;          // 1-tile T-frag of dL/d raw_density (row 0); SAR rows 0..2: g*rstd, g*rstd*mean, g
 };
 
 // One backward layer: NT output tiles (features of the layer INPUT), reduction over KS_M k-steps of
 // `gm` (the layer's dY) then KS_E of `ge`.  MASKED: zero the units whose saved pre-activation was negative,
 // by the sign words in `keepw` (loaded a layer ahead, so that the load is old by the time it is waited for
 // and does not drain the fetches and stores queued behind it).  The first stage loads the next layer's words.
-template <class N, int STAGE0, int NT, int KS_M, int KS_E, bool MASKED, int NW_NEXT, int KM, int KE, int KO, int KW, int KWN>
+template <class N, int STAGE0, int NT, int KS_M, int KS_E, bool MASKED, int NW_NEXT, bool LNFIX = false, int KM, int KE, int KO, int KW, int KWN, int KX = 1>
 __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[KM], const bf16x8 (&ge)[KE],
                                           bf16x8 (&out)[KO], const unsigned (&keepw)[KW], const unsigned* next_mask,
-                                          unsigned (&nextw)[KWN], bf16x8* tdy, int64_t b32, const bf16x8 (&P)[2]) {
+                                          unsigned (&nextw)[KWN], bf16x8* tdy, int64_t b32, const bf16x8 (&P)[2],
+                                          const bf16x8 (&x7)[KX] = {}, float c0 = 0.f, float c1 = 0.f) {
     constexpr int KS = KS_M + KS_E;
     const int lane = pipe.lane;
 #define NERF_BS(i) bwd_stage<N>(i)
     constexpr int NS = stage_count(NT);
     static_assert(NERF_BS(STAGE0).ks == KS * (NT < kTPS ? NT : kTPS) && NERF_BS(STAGE0).xloads == NW_NEXT,
                   "stage table out of step");
-    auto finish = [&](auto ntc, const f32x16& acc) __attribute__((always_inline)) {
+    auto finish = [&](auto ntc, const f32x16& raw) __attribute__((always_inline)) {
         constexpr int nt = decltype(ntc)::value;
+        f32x16 acc = raw;
+        if constexpr (LNFIX) {      // LayerNorm backward: the terms through the mean and the variance, c0 + c1 * x
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[8 * s + j] += c0 + c1 * (float)x7[2 * nt + s][j];
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 o = pack_bf16x8(acc, 8 * s);
@@ -602,7 +621,6 @@ __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[K
 
 template <class N>
 __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
-    static_assert(!N::SAR, "the SAR head's backward chain is not instantiated");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -624,13 +642,41 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
     bf16x8 dz, dd, zero;
 #pragma unroll
     for (int j = 0; j < 8; ++j) dz[j] = dd[j] = zero[j] = (__bf16)0.f;
-    if (ok && h == 0) {
+    float c0 = 0.f, c1 = 0.f;                        // SAR: per-sample LayerNorm backward coefficients
+    bf16x8 x7[N::SAR ? HKS : 1];
+    if constexpr (N::SAR) {
 #pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            const float sg = a.raw_rgb[m * 3 + o];
-            dz[o] = (__bf16)(a.g_rgb[m * 3 + o] * sg * (1.f - sg));
+        for (int ks = 0; ks < HKS; ++ks) x7[ks] = a.x7_frag[((blk * HKS + ks) * 2 + ct) * 64 + lane];
+    }
+    if (ok) {
+        float gd = a.g_density[m];
+        if constexpr (N::SAR) {
+            // d = rstd * (S1 - mean * S0) + c with S1 = sum_f (w gamma)_f x_f, S0 = sum_f (w gamma)_f:
+            // dL/dx_f = g [ rstd (w gamma)_f - rstd S0 / H - rstd^2 (d - c) (x_f - mean) / H ]
+            const float* sc = a.consts + N::C_SC;
+            const float mean = a.ln_stats[m * 2 + 0], rstd = a.ln_stats[m * 2 + 1];
+            const float A = gd * rstd * sc[6] * sc[8];
+            const float B = gd * rstd * rstd * (a.raw_density[m] - sc[7]) * sc[8];
+            c1 = -B;
+            c0 = B * mean - A;
+            if (h == 0) {
+                dd[1] = (__bf16)(gd * rstd * mean);
+                dd[2] = (__bf16)gd;
+            }
+            gd *= rstd;
         }
-        dd[0] = (__bf16)a.g_density[m];
+        if (h == 0) {
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float sg = a.raw_rgb[m * 3 + o];
+                dz[o] = (__bf16)(a.g_rgb[m * 3 + o] * sg * (1.f - sg));
+            }
+            dd[0] = (__bf16)gd;
+        }
+        if constexpr (N::SAR) {     // angle heads: rows 3 (lane half 0, element 3) and 4 (lane half 1, element 0)
+            const float sg = a.raw_angle[m * 2 + h];
+            dz[h == 0 ? 3 : 0] = (__bf16)(a.g_angle[m * 2 + h] * sg * (1.f - sg));
+        }
     }
     unsigned kw9[WW], kwa[HW], kwb[HW], nokw[1] = {0u};
 #pragma unroll
@@ -652,7 +698,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
     // rgb_net1^T (rows of X8 only): dY8 = W9[:, :H]^T dY9   (rgb_net0 has no activation)
     bwd_layer<N, WS, HT, WKS, 0, false, HW>(pipe, gw, none, ga, nokw, a.mask[7], kwa, a.tdy[8], b32, P);
     // [rgb_net0 ; density head]^T: dX7 = W8^T dY8 + wd^T dd, masked by X7 > 0 -> dY7
-    bwd_layer<N, WS + 1 * HS, HT, HKS, 1, true, HW>(pipe, ga, ddv, gb, kwa, a.mask[6], kwb, a.tdy[7], b32, P);
+    bwd_layer<N, WS + 1 * HS, HT, HKS, 1, true, HW, N::SAR>(pipe, ga, ddv, gb, kwa, a.mask[6], kwb, a.tdy[7], b32, P, x7, c0, c1);
     bwd_layer<N, WS + 2 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[5], kwa, a.tdy[6], b32, P);
     bwd_layer<N, WS + 3 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[4], kwb, a.tdy[5], b32, P);
     bwd_layer<N, WS + 4 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[3], kwa, a.tdy[4], b32, P);
@@ -1033,7 +1079,9 @@ static inline bool make_dims(const nerf_mlp_dims* d, HostDims* o) {
     X(8, 4, 4, 2, false)        /* H=256 W=128 L=10 (64+128 configuration) */ \
     X(8, 2, 4, 2, false)        /* H=256 W=64  L=10 (64+64 configuration)  */ \
     X(8, 4, 6, 2, false)        /* H=256 W=128 L=16 (params.yaml nerf)     */ \
-    X(2, 1, 2, 2, false)        /* H=64  W<=32 L=4  (small test network)   */
+    X(2, 1, 2, 2, false)        /* H=64  W<=32 L=4  (small test network)   */ \
+    X(5, 6, 2, 2, true)         /* SAR: H=156 W=180 L=4 (params.yaml sar)  */ \
+    X(2, 1, 2, 2, true)         /* SAR: H=64  W<=32 L=4 (small test net)   */
 
 template <class N, bool SAVE>
 static int launch_fwd_t(const MlpFwdArgs& a, hipStream_t st) {
@@ -1148,7 +1196,7 @@ extern "C" int nerf_view_frag(const float* dirs, int64_t n_rays, int min_deg, in
 
 extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* consts, const void* enc_frag,
                             const void* view_frag, int64_t n_samples, int ray_div, int64_t n_rays,
-                            void* const* acts /* 22 pointers or NULL */, float* raw_density,
+                            void* const* acts /* 22 (SAR: 23) pointers or NULL */, float* raw_density,
                             float* raw_rgb, float* raw_angle, float* ln_stats, void* stream) {
     if (n_samples == 0) return NERF_OK;
     HostDims d;
@@ -1171,7 +1219,9 @@ extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const f
     }
     a.t_enc = acts ? (bf16x8*)acts[20] : nullptr;
     a.t_view = acts ? (bf16x8*)acts[21] : nullptr;
+    a.x7_frag = (acts && d.sar) ? (bf16x8*)acts[22] : nullptr;
     if (acts) for (int i = 0; i < 22; ++i) NERF_REQUIRE(acts[i] != nullptr || i == 18);
+    if (acts && d.sar) NERF_REQUIRE(acts[22] != nullptr);
     a.raw_density = raw_density;
     a.raw_rgb = raw_rgb;
     a.raw_angle = raw_angle;
@@ -1198,21 +1248,24 @@ static int launch_bwd(const MlpBwdArgs& a, hipStream_t st) {
     return nerf_launch_status();
 }
 
-extern "C" int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, int64_t n_samples, const float* g_density,
-                            const float* g_rgb, const float* g_angle, const float* raw_rgb, const float* raw_angle,
-                            const float* ln_stats, void* const* acts /* as nerf_mlp_fwd */,
+extern "C" int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, const float* consts, int64_t n_samples,
+                            const float* g_density, const float* g_rgb, const float* g_angle, const float* raw_density,
+                            const float* raw_rgb, const float* raw_angle, const float* ln_stats,
+                            void* const* acts /* as nerf_mlp_fwd */,
                             void* const* dys /* 12 T-frag buffers: dY0..dY9, colour head tile, density head tile */,
                             void* stream) {
     if (n_samples == 0) return NERF_OK;
     HostDims d;
     NERF_REQUIRE(make_dims(dims, &d) && wbwd && g_density && g_rgb && raw_rgb && acts && dys && n_samples > 0);
-    if (d.sar) return NERF_ERR_SIZE;   // SAR heads train on the fp32 path
+    if (d.sar) NERF_REQUIRE(consts && g_angle && raw_density && raw_angle && ln_stats && acts[22]);
     MlpBwdArgs a;
     a.wbwd = (const bf16x8*)wbwd;
     a.M = n_samples;
     a.nblk = ((n_samples + 255) / 256) * 4;
     a.g_density = g_density; a.g_rgb = g_rgb; a.g_angle = g_angle;
     a.raw_rgb = raw_rgb; a.raw_angle = raw_angle; a.ln_stats = ln_stats;
+    a.raw_density = raw_density; a.consts = consts;
+    a.x7_frag = d.sar ? (const bf16x8*)acts[22] : nullptr;
     for (int i = 0; i < 10; ++i) {
         NERF_REQUIRE((acts[10 + i] || i == 8) && dys[i]);
         a.mask[i] = (const unsigned*)acts[10 + i];
@@ -1222,8 +1275,8 @@ extern "C" int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, int64_t
     a.tdy_hd = (bf16x8*)dys[10];
     a.tdy_dens = (bf16x8*)dys[11];
 #define X(ht_, wt_, dks_, vks_, sar_)                                                            \
-    if (!sar_ && d.HT == ht_ && d.WT == wt_ && d.DKS == dks_ && d.VKS == vks_ && d.sar == 0)      \
-        return launch_bwd<Net<ht_, wt_, dks_, vks_, false>>(a, nerf_stream(stream));
+    if (d.HT == ht_ && d.WT == wt_ && d.DKS == dks_ && d.VKS == vks_ && (d.sar != 0) == sar_)     \
+        return launch_bwd<Net<ht_, wt_, dks_, vks_, sar_>>(a, nerf_stream(stream));
     NERF_NET_LIST(X)
 #undef X
     return NERF_ERR_SIZE;

@@ -19,7 +19,7 @@ _lib.register('nerf_view_frag', c_int, [_P, c_int64, c_int, c_int, _P, _P])
 _lib.register('nerf_mlp_fwd', c_int, [POINTER(MlpDims), _P, _P, _P, _P, c_int64, c_int, c_int64, POINTER(c_void_p),
                                       _P, _P, _P, _P, _P])
 
-_lib.register('nerf_mlp_bwd', c_int, [POINTER(MlpDims), _P, c_int64, _P, _P, _P, _P, _P, _P, POINTER(c_void_p),
+_lib.register('nerf_mlp_bwd', c_int, [POINTER(MlpDims), _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, POINTER(c_void_p),
                                       POINTER(c_void_p), _P])
 class WgradDesc(ctypes.Structure):
     """nerf_wgrad_desc of include/nerf_amd.h."""
@@ -129,12 +129,15 @@ def _wgrad_plan(pk):
               [[('density_net1.0', 0), ('density_net1.0', H)]])]
     plan += [one(l, HP, H, 'density_net1.%d' % i, ('x', l - 1), HP, H) for l, i in ((5, 2), (6, 4), (7, 6))]
     # rgb_net0 and the density head both read the trunk output X7
-    plan += [([(8, HP, H, 'rgb_net0.0'), (11, 32, 1, 'final_density.0')], [(('x', 7), HP, H)],
-              [[('rgb_net0.0', 0)], [('final_density.0', 0)]])]
+    # (SAR: the density tile carries rows g*rstd, g*rstd*mean, g; they land in the scratch pair '_dens')
+    dens = ('_dens', 3) if pk.sar else ('final_density.0', 1)
+    plan += [([(8, HP, H, 'rgb_net0.0'), (11, 32, dens[1], dens[0])], [(('x', 7), HP, H)],
+              [[('rgb_net0.0', 0)], [(dens[0], 0)]])]
     # rgb_net1.0 takes [X8 | view features]
     plan += [([(9, WP, W, 'rgb_net1.0')], [(('x', 8), HP, H), ('view', VP, V)],
               [[('rgb_net1.0', 0), ('rgb_net1.0', H)]])]
-    plan += [one(10, 32, 3, 'final_rgb.0', ('x', 9), WP, W)]
+    # (SAR: rows 0..2 final_rgb, 3..4 final_angle, in the scratch pair '_heads')
+    plan += [one(10, 32, 5, '_heads', ('x', 9), WP, W) if pk.sar else one(10, 32, 3, 'final_rgb.0', ('x', 9), WP, W)]
     return plan
 
 
@@ -188,7 +191,9 @@ def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False):
                  for i, t in enumerate(tiles)]
         acts += [torch.empty(nblk * pk.DT * 4096, dtype=torch.uint8, device=dev),
                  torch.empty(nblk * pk.VT * 4096, dtype=torch.uint8, device=dev)]
-        arr = (c_void_p * 22)(*[a.data_ptr() if a is not None else None for a in acts])
+        if pk.sar:       # 22: the trunk output once more in frag order, for the LayerNorm backward
+            acts.append(torch.empty(nblk * 32 * pk.HT * 128, dtype=torch.uint8, device=dev))
+        arr = (c_void_p * len(acts))(*[a.data_ptr() if a is not None else None for a in acts])
     with profiling.timed('mlp_fwd_kernel', flops=pk.fwd_flops * n_samples):
         check(lib().nerf_mlp_fwd(ctypes.byref(pk.dims), _raw(pk.wfwd), ptr(pk.consts), _raw(enc), _raw(view),
                                  n_samples, ray_div, n_rays, arr, ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
@@ -196,18 +201,23 @@ def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False):
     return raw_density, raw_rgb, raw_angle, acts, ln_stats
 
 
-def mlp_backward(pk, acts, n_samples, g_density, g_rgb, raw_rgb):
-    """Backward chain -> list of 12 dY T-frag buffers (dY0..dY9, colour head tile, density head tile)."""
+def mlp_backward(pk, acts, n_samples, g_density, g_rgb, raw_rgb, g_angle=None, raw_density=None, raw_angle=None,
+                 ln_stats=None):
+    """Backward chain -> list of 12 dY T-frag buffers (dY0..dY9, colour head tile, density head tile).
+    The SAR heads also need the angle gradient and the forward's density / angle outputs and LayerNorm statistics."""
     dev = g_density.device
     nblk = n_blocks(n_samples)
     tiles = [pk.HT] * 9 + [pk.WT, 1, 1]
     dys = [torch.empty(nblk * t * 4096, dtype=torch.uint8, device=dev) for t in tiles]
-    a_arr = (c_void_p * 22)(*[a.data_ptr() if a is not None else None for a in acts])
+    a_arr = (c_void_p * len(acts))(*[a.data_ptr() if a is not None else None for a in acts])
     d_arr = (c_void_p * 12)(*[d.data_ptr() for d in dys])
     g_density, g_rgb = f32c(g_density).reshape(-1), f32c(g_rgb).reshape(-1, 3)
+    if pk.sar:
+        g_angle = f32c(g_angle).reshape(-1, 2)
     with profiling.timed('mlp_bwd_kernel', flops=pk.bwd_dx_flops * n_samples):
-        check(lib().nerf_mlp_bwd(ctypes.byref(pk.dims), _raw(pk.wbwd), n_samples, ptr(g_density), ptr(g_rgb), None,
-                                 ptr(raw_rgb), None, None, a_arr, d_arr, stream()))
+        check(lib().nerf_mlp_bwd(ctypes.byref(pk.dims), _raw(pk.wbwd), ptr(pk.consts), n_samples, ptr(g_density),
+                                 ptr(g_rgb), ptr(g_angle), ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
+                                 ptr(ln_stats), a_arr, d_arr, stream()))
     return dys
 
 
@@ -290,3 +300,57 @@ def query_nerf(model, t_vals, rays, viewf, S):
     p = dict(model.named_parameters())
     params = [p[k] for k in PARAM_NAMES]
     return _MlpNerf.apply(model, encf, viewf, n * S, S, n, *params)
+
+
+SAR_PARAM_NAMES = [n + s for n in STREAMED + ['final_density.0', 'final_density.1', 'final_rgb.0', 'final_angle.0']
+                   for s in ('.weight', '.bias')]
+
+
+class _MlpSar(torch.autograd.Function):
+    """raw_density [M,1], raw_rgb [M,3], angle [M,2] = SAR MLP(enc frags, view frags) (model.py:343-359);
+    gradients flow to the 28 parameters, the LayerNorm pair and the density weight through the rows the
+    backward chain leaves in the density head tile."""
+
+    @staticmethod
+    def forward(ctx, model, encf, viewf, n_samples, ray_div, n_rays, *params):
+        need_grad = any(ctx.needs_input_grad[6:])
+        pk = packed_for(model, need_bwd=need_grad)
+        d, rgb, ang, acts, ln = mlp_forward(pk, encf, viewf, n_samples, ray_div, n_rays, save=need_grad)
+        ctx.pk, ctx.acts, ctx.n = pk, acts, n_samples
+        ctx.params = {n: p.detach() for n, p in zip(SAR_PARAM_NAMES, params)}
+        ctx.save_for_backward(d, rgb, ang, ln)
+        return d.reshape(-1, 1), rgb, ang
+
+    @staticmethod
+    def backward(ctx, g_density, g_rgb, g_angle):
+        d, rgb, ang, ln = ctx.saved_tensors
+        pk, P = ctx.pk, ctx.params
+        dys = mlp_backward(pk, ctx.acts, ctx.n, g_density, g_rgb, rgb, g_angle, d, ang, ln)
+        dev = d.device
+        grads = {n: torch.zeros_like(P[n]) for n in SAR_PARAM_NAMES}
+        grads['_dens.weight'], grads['_dens.bias'] = torch.zeros(3, pk.H, device=dev), torch.zeros(3, device=dev)
+        grads['_heads.weight'], grads['_heads.bias'] = torch.zeros(5, pk.W, device=dev), torch.zeros(5, device=dev)
+        mlp_weight_grads(pk, ctx.acts, dys, ctx.n, grads)
+        ctx.acts = None
+        # d = sum_f w_f (gamma_f xhat_f + beta_f) + b, xhat = (x - mean) rstd:
+        # A_f = sum_m g rstd x_f, B = sum_m g rstd mean, Sg = sum_m g  ->  dL/d(w gamma)_f = A_f - B
+        gamma, beta = P['final_density.0.weight'], P['final_density.0.bias']
+        w = P['final_density.1.weight'][0]
+        du = grads['_dens.weight'][0] - grads['_dens.bias'][1]
+        sg = grads['_dens.bias'][2]
+        grads['final_density.1.weight'] = (gamma * du + beta * sg)[None]
+        grads['final_density.1.bias'] = sg[None]
+        grads['final_density.0.weight'] = w * du
+        grads['final_density.0.bias'] = w * sg
+        grads['final_rgb.0.weight'], grads['final_rgb.0.bias'] = grads['_heads.weight'][:3], grads['_heads.bias'][:3]
+        grads['final_angle.0.weight'], grads['final_angle.0.bias'] = grads['_heads.weight'][3:], grads['_heads.bias'][3:]
+        return (None, None, None, None, None, None) + tuple(grads[n] for n in SAR_PARAM_NAMES)
+
+
+def query_sar(model, t_vals, origins, ray_d, radii, viewf, R, S):
+    """One level of the SAR MLP on the bf16 path.  Row i takes the view features of ray i mod R, as upstream's
+    tiling does (model.py:351-354)."""
+    cfg = model.config
+    encf = encode_frag(t_vals, origins, ray_d, radii, model.ray_shape, cfg.min_deg, cfg.max_deg)
+    p = dict(model.named_parameters())
+    return _MlpSar.apply(model, encf, viewf, R * S, R, R, *[p[k] for k in SAR_PARAM_NAMES])

@@ -5,8 +5,8 @@ load and `torch.save(model.state_dict())` is interchangeable) and the same publi
 `train_val_get`, `train`, `eval`) -- model.py:26-216, 228-428 -- running on the HIP kernels.
 
 The `nn.Linear` / `nn.LayerNorm` submodules only *hold* the parameters; their `forward` is never
-called.  `config.mlp_precision` selects the MLP path: 'bf16' (fused MFMA chain, default) or
-'fp32' (layer-by-layer fp32 matrix-core GEMMs).  `config.level_samples` (optional list) gives the
+called.  `config.mlp_precision` selects the MLP path: 'fp32' (layer-by-layer fp32 matrix-core GEMMs, default,
+1e-4 parity) or 'bf16' (fused MFMA chain, 2e-2 parity).  `config.level_samples` (optional list) gives the
 number of intervals per level; upstream uses `config.num_samples` for every level.
 
 The reference subclasses pytorch_lightning.LightningModule; this module only needs `device`,
@@ -323,7 +323,12 @@ class SARNeRF(_RenderModule):
                 az = torch.randn(R) * SAR_AZ_SIGMA
                 el = torch.randn(R) * SAR_EL_SIGMA
             ray_d, ray_p = ops.sar_raygen(az.to(dev), el.to(dev))
-            view_feat = ops.pe_encode(ray_d, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg, append_input=True)
+            bf16 = self._precision() == 'bf16'
+            if bf16:
+                from . import mlp_bf16
+                view_feat = mlp_bf16.view_frag(ray_d, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg)
+            else:
+                view_feat = ops.pe_encode(ray_d, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg, append_input=True)
             t_vals = weights = None
             for l in range(L):
                 with torch.no_grad():
@@ -338,9 +343,13 @@ class SARNeRF(_RenderModule):
                             ur = (u_rand[c] if u_rand is not None else
                                   torch.empty(R, S + 1, device=dev).uniform_(0, 1 / (S + 1) - float(torch.finfo(torch.float32).eps)))
                         t_vals = ops.resample(t_vals, weights, S + 1, self.resample_padding, ur, blur=True)
-                    mean, cov = ops.cast_rays(t_vals, origins, ray_d, radii, self.ray_shape)
-                    enc = ops.ipe_encode(mean, cov, cfg.min_deg, cfg.max_deg).reshape(R * S, -1)
-                raw_density, raw_rgb, angle = self._query(enc, view_feat, R, S)
+                    if not bf16:
+                        mean, cov = ops.cast_rays(t_vals, origins, ray_d, radii, self.ray_shape)
+                        enc = ops.ipe_encode(mean, cov, cfg.min_deg, cfg.max_deg).reshape(R * S, -1)
+                if bf16:        # cast + encoding fused into the operand fragments of the MFMA chain
+                    raw_density, raw_rgb, angle = mlp_bf16.query_sar(self, t_vals, origins, ray_d, radii, view_feat, R, S)
+                else:
+                    raw_density, raw_rgb, angle = self._query(enc, view_feat, R, S)
                 if self.randomized and self.density_noise:
                     raw_density = raw_density + self.density_noise * torch.rand(raw_density.shape, device=dev)
                 pulse, distance, acc, weights, alpha, _, status = ops.scatter(
