@@ -98,6 +98,8 @@ def main():
     ap.add_argument('--chunk', type=int, default=65536, help='rays per forward/backward chunk')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='c3', choices=['c3', 'c2'],
+                    help="c3 (default, the headline metric): full train step; c2: forward-only render (use --rays 1048576)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -128,6 +130,9 @@ def main():
     mask_sum = rays.lossmult.sum() * world
 
     def step():
+        if args.workload == 'c2':                   # coarse+fine render only, nothing saved for a backward pass
+            with torch.no_grad():
+                return model(rays)[0].sum()
         return nerf_train_step(model, rays, pixels, opt, chunk=args.chunk, world_size=world, global_mask_sum=mask_sum)
 
     def fence():
@@ -155,10 +160,12 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = args.rays * world * args.steps / dt
         out = {
-            'metric': 'rays/sec fwd+bwd (64+128 samples/ray)', 'value': value, 'unit': 'rays/s', 'n_gpus': world,
+            'metric': 'rays/sec fwd+bwd (64+128 samples/ray)' if args.workload == 'c3' else 'rays/sec fwd (64+128 samples/ray)',
+            'value': value, 'unit': 'rays/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
-            'config': {'workload': 'C3: full NeRF train step (fwd+bwd+AdamW), coarse 64 + fine 128 samples/ray, '
+            'config': {'workload': ('C3: full NeRF train step (fwd+bwd+AdamW)' if args.workload == 'c3' else
+                                    'C2: forward-only hierarchical render') + ', coarse 64 + fine 128 samples/ray, '
                                    '8x256 MLP (colour width 128), L=10/4 posenc',
                        'rays_per_step_per_gpu': args.rays, 'global_rays_per_step': args.rays * world,
                        'chunk_rays': args.chunk, 'parallelism': f'ray-sharded dp{world}, flat-bucket grad all-reduce',
@@ -185,7 +192,7 @@ def main():
             mlp_ms = sum(prof[k]['ms'] for k in prof if k.startswith('mlp_'))
             if mlp_ms > 0:
                 out['mlp_mfma_util'] = mlp_flops / (mlp_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'c3':
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -299,6 +299,9 @@ def query_nerf(model, t_vals, rays, viewf, S):
     encf = encode_frag(t_vals, rays.origins, rays.directions, rays.radii, model.ray_shape, cfg.min_deg, cfg.max_deg)
     p = dict(model.named_parameters())
     params = [p[k] for k in PARAM_NAMES]
+    if not (torch.is_grad_enabled() and any(q.requires_grad for q in params)):      # inference: nothing saved
+        d, rgb, _, _, _ = mlp_forward(packed_for(model, need_bwd=False), encf, viewf, n * S, S, n, save=False)
+        return d.reshape(-1, 1), rgb
     return _MlpNerf.apply(model, encf, viewf, n * S, S, n, *params)
 
 
@@ -353,4 +356,8 @@ def query_sar(model, t_vals, origins, ray_d, radii, viewf, R, S):
     cfg = model.config
     encf = encode_frag(t_vals, origins, ray_d, radii, model.ray_shape, cfg.min_deg, cfg.max_deg)
     p = dict(model.named_parameters())
-    return _MlpSar.apply(model, encf, viewf, R * S, R, R, *[p[k] for k in SAR_PARAM_NAMES])
+    params = [p[k] for k in SAR_PARAM_NAMES]
+    if not (torch.is_grad_enabled() and any(q.requires_grad for q in params)):      # inference: nothing saved
+        d, rgb, ang, _, _ = mlp_forward(packed_for(model, need_bwd=False), encf, viewf, R * S, R, R, save=False)
+        return d.reshape(-1, 1), rgb, ang
+    return _MlpSar.apply(model, encf, viewf, R * S, R, R, *params)
