@@ -27,6 +27,8 @@
 // Kernels: weight packing (forward and transposed streams), fused cast+IPE encoder and view-feature
 // encoder emitting frags, the forward chain, the backward chain (dX through all layers, emitting dY
 // T-frags) and the streaming weight-gradient GEMM.  bf16 inputs, fp32 accumulation and epilogues.
+#include <atomic>
+
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -1083,15 +1085,22 @@ static inline bool make_dims(const nerf_mlp_dims* d, HostDims* o) {
     X(5, 6, 2, 2, true)         /* SAR: H=156 W=180 L=4 (params.yaml sar)  */ \
     X(2, 1, 2, 2, true)         /* SAR: H=64  W<=32 L=4 (small test net)   */
 
+// Raise a kernel's dynamic-LDS limit once per device (the attribute belongs to the device's copy of the code
+// object; a process may drive several devices).
+static bool allow_dynamic_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done_mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    const unsigned long long bit = 1ull << dev;
+    if (done_mask.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done_mask.fetch_or(bit, std::memory_order_release);
+    return true;
+}
+
 template <class N, bool SAVE>
 static int launch_fwd_t(const MlpFwdArgs& a, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)mlp_fwd_kernel<N, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                N::FWD_LDS) != hipSuccess)
-            return NERF_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> done{0};
+    if (!allow_dynamic_lds((const void*)mlp_fwd_kernel<N, SAVE>, N::FWD_LDS, done)) return NERF_ERR_LAUNCH;
     hipLaunchKernelGGL((mlp_fwd_kernel<N, SAVE>), dim3((unsigned)(a.nblk / 4)), dim3(64 * kWaves), N::FWD_LDS, st, a);
     return nerf_launch_status();
 }
@@ -1236,14 +1245,9 @@ extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const f
 
 template <class N>
 static int launch_bwd(const MlpBwdArgs& a, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> done{0};
     constexpr int lds = N::BWD_LDS;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)mlp_bwd_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess)
-            return NERF_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (!allow_dynamic_lds((const void*)mlp_bwd_kernel<N>, lds, done)) return NERF_ERR_LAUNCH;
     hipLaunchKernelGGL((mlp_bwd_kernel<N>), dim3((unsigned)(a.nblk / 4)), dim3(64 * kWaves), lds, st, a);
     return nerf_launch_status();
 }
@@ -1312,13 +1316,8 @@ extern "C" int nerf_mlp_wgrad_config(int n_feat, int k_feat, int* nw, int* tn, i
 
 template <int NW, int NTW, int KTW>
 static int launch_wgrad(const WgradArgs& a, unsigned grid, size_t lds, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)mlp_wgrad_kernel<NW, NTW, KTW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kWgradLds) != hipSuccess)
-            return NERF_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> done{0};
+    if (!allow_dynamic_lds((const void*)mlp_wgrad_kernel<NW, NTW, KTW>, kWgradLds, done)) return NERF_ERR_LAUNCH;
     hipLaunchKernelGGL((mlp_wgrad_kernel<NW, NTW, KTW>), dim3(grid), dim3(64 * NW), lds, st, a);
     return nerf_launch_status();
 }
