@@ -761,11 +761,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
     LDS_AS char* ring = (LDS_AS char*)smem;
     const int depth = a.depth;
     LDS_AS char* scratch = ring + depth * slot_bytes;  // landing zone of the padding loads
-    // k-steps are dealt round-robin: at any moment the workgroups together sweep one contiguous window of
-    // each operand (grid * NT KiB), which spreads over all HBM channels; contiguous per-workgroup ranges
-    // would put every workgroup on the same channel at the same time.
+    // k-steps are dealt round-robin in pairs (16 samples x 2): at any moment the workgroups together sweep one
+    // contiguous window of each operand, which spreads over all HBM channels (contiguous per-workgroup ranges would
+    // put every workgroup on the same channel at the same time); a.nq is even, so every workgroup's count is too.
     const int64_t q0 = blockIdx.x, qstride = gridDim.x;
-    const int64_t n = q0 < a.nq ? (a.nq - q0 + qstride - 1) / qstride : 0;
+    const int64_t npairs = a.nq / 2;
+    const int64_t n = q0 < npairs ? 2 * ((npairs - q0 + qstride - 1) / qstride) : 0;
     f32x16 acc[NTW][KTW];
     float accb[NTW];                                   // bias gradient: this lane's feature, its half of the samples
 #pragma unroll
@@ -800,7 +801,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
     }
     int fill = 0, drain = 0;                           // ring positions of the next k-step to load / to consume
     auto issue = [&](int64_t i) {
-        const int64_t q = q0 + i * qstride;
+        const int64_t q = 2 * (q0 + (i >> 1) * qstride) + (i & 1);
         LDS_AS char* slot = ring + (unsigned)fill * slot_bytes;
         fill = fill + 1 == depth ? 0 : fill + 1;
         const bool live = i < n;
@@ -815,15 +816,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
         }
     };
 
-    const int in_flight = (depth - 2) * G;
-    for (int i = 0; i < depth - 1; ++i) issue(i);
-    for (int64_t i = 0; i < n; ++i) {
-        wait_vmcnt(in_flight);
-        __builtin_amdgcn_s_barrier();
-        issue(i + depth - 1);
-        LDS_AS const char* slot = ring + (unsigned)drain * slot_bytes;
-        drain = drain + 1 == depth ? 0 : drain + 1;
-        bf16x8 A[NTW], B[KTW];
+    auto read_operands = [&](LDS_AS const char* slot, bf16x8 (&A)[NTW], bf16x8 (&B)[KTW]) {
 #pragma unroll
         for (int ii = 0; ii < NTW; ++ii) {
             const int nt = wn * NTW + ii;
@@ -834,19 +827,60 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
             const int kt = wk * KTW + j;
             B[j] = *(LDS_AS const bf16x8*)(slot + (a.NT + (kt < a.KT ? kt : 0)) * 1024 + lane * 16);
         }
+    };
+    // MFMAs of one k-step; the column sums of dY (bias gradient) ride along on the vector ALU, branch-free so that
+    // they are scheduled between the MFMAs (waves that do not own the bias just do not flush them)
+    auto multiply = [&](const bf16x8 (&A)[NTW], const bf16x8 (&B)[KTW]) {
 #pragma unroll
-        for (int ii = 0; ii < NTW; ++ii)
+        for (int ii = 0; ii < NTW; ++ii) {
 #pragma unroll
             for (int j = 0; j < KTW; ++j) acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ii], B[j], acc[ii][j], 0, 0, 0);
-        if (do_bias) {                                  // column sums of dY on the vector ALU, under the MFMAs
+            const u32x4 d = __builtin_bit_cast(u32x4, A[ii]);
+            float t = 0.f;
 #pragma unroll
-            for (int ii = 0; ii < NTW; ++ii) {
-                const u32x4 d = __builtin_bit_cast(u32x4, A[ii]);
-                float t = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) t += __uint_as_float(d[q] << 16) + __uint_as_float(d[q] & 0xffff0000u);
-                accb[ii] += t;
-            }
+            for (int q = 0; q < 4; ++q) t += __uint_as_float(d[q] << 16) + __uint_as_float(d[q] & 0xffff0000u);
+            accb[ii] += t;
+        }
+    };
+    auto slot_of = [&](int pos) { return ring + (unsigned)pos * slot_bytes; };
+    auto next_pos = [&](int pos) { return pos + 1 == depth ? 0 : pos + 1; };
+
+    for (int i = 0; i < depth - 1; ++i) issue(i);
+    if constexpr (NW == 4) {
+        // One wave per SIMD: nothing but this wave's own instruction stream hides LDS latency, so the operand reads
+        // run one k-step ahead of the MFMAs.  At the top of iteration i, k-step i is in registers and k-step i+1 has
+        // landed; two iterations per trip so the two register sets need no copies.
+        bf16x8 A0[NTW], B0[KTW], A1[NTW], B1[KTW];
+        if (n > 0) {
+            wait_vmcnt((depth - 2) * G);
+            __builtin_amdgcn_s_barrier();
+            read_operands(slot_of(0), A0, B0);
+        }
+        const int in_flight = (depth - 3) * G;
+        for (int64_t i = 0; i < n; i += 2) {            // n is even
+            wait_vmcnt(in_flight);                      // this wave's pieces of k-step i+1 have landed
+            __builtin_amdgcn_s_barrier();               // everyone's have; everyone is done reading k-step i's slot
+            issue(i + depth - 1);
+            drain = next_pos(drain);
+            read_operands(slot_of(drain), A1, B1);      // k-step i+1
+            multiply(A0, B0);
+            wait_vmcnt(in_flight);
+            __builtin_amdgcn_s_barrier();
+            issue(i + depth);
+            drain = next_pos(drain);
+            read_operands(slot_of(drain), A0, B0);      // k-step i+2 (unused garbage past the end)
+            multiply(A1, B1);
+        }
+    } else {
+        const int in_flight = (depth - 2) * G;
+        for (int64_t i = 0; i < n; ++i) {
+            wait_vmcnt(in_flight);
+            __builtin_amdgcn_s_barrier();
+            issue(i + depth - 1);
+            bf16x8 A[NTW], B[KTW];
+            read_operands(slot_of(drain), A, B);
+            drain = next_pos(drain);
+            multiply(A, B);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS write may outlive the workgroup
@@ -872,7 +906,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
                 if (nn < a.A[sa].n_true) atomicAdd(&o.G[(int64_t)nn * o.ld + o.col0 + k], acc[i][j][r]);
             }
         }
-        if (do_bias && a.gb[sa] != nullptr) {
+        if (do_bias && a.gb[sa] != nullptr) {           // both lane halves: they hold different samples
             const int nn = lt * 32 + c;
             if (nn < a.A[sa].n_true) atomicAdd(&a.gb[sa][nn], accb[i]);
         }
@@ -1350,6 +1384,7 @@ extern "C" int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples,
     if (loads > 5) return NERF_ERR_SIZE;
     a.depth = (kWgradLds / 1024 - nw) / pieces;
     if ((a.depth - 2) * loads > 63) a.depth = 63 / loads + 2;
+    if (a.depth < 3) return NERF_ERR_SIZE;
     const size_t lds = (size_t)(a.depth * pieces + nw) * 1024;
     hipStream_t st = nerf_stream(stream);
     if (nw == 8) return tn == 4 ? launch_wgrad<8, 4, 3>(a, grid, lds, st) : launch_wgrad<8, 5, 2>(a, grid, lds, st);

@@ -222,6 +222,7 @@ def mlp_backward(pk, acts, n_samples, g_density, g_rgb, raw_rgb, g_angle=None, r
 
 
 _WGRAD_KERNEL = {}
+WGRAD_GRID = 0          # workgroups per weight-gradient launch; 0 = one per compute unit
 
 
 def wgrad_kernel_name(n_feat, k_feat):
@@ -262,7 +263,7 @@ def mlp_weight_grads(pk, acts, dys, n_samples, grads):
         nf_all, kf_all = sum(s[1] for s in dsegs), sum(s[1] for s in xsegs)
         # algorithmic work of the launch: every operand byte once, 2 FLOP per true multiply-add
         with profiling.timed(wgrad_kernel_name(nf_all, kf_all), flops=flops, bytes_=2.0 * (nf_all + kf_all) * n_samples):
-            check(lib().nerf_mlp_wgrad_multi(ctypes.byref(d), n_samples, 0, stream()))
+            check(lib().nerf_mlp_wgrad_multi(ctypes.byref(d), n_samples, WGRAD_GRID, stream()))
 
 
 PARAM_NAMES = [n + s for n in STREAMED + ['final_density.0', 'final_rgb.0'] for s in ('.weight', '.bias')]
