@@ -141,10 +141,19 @@ def _wgrad_plan(pk):
     return plan
 
 
+def _param_versions(model):
+    # torch bumps a tensor's version on every in-place write (optimizer steps, load_state_dict, .copy_), and
+    # data_ptr changes when a parameter is replaced: together they identify the weights the streams were packed from
+    return tuple((p.data_ptr(), p._version) for p in model.parameters())
+
+
 def packed_for(model, need_bwd=True):
+    """The packed bf16 streams of `model`, re-packed whenever a parameter has been written since the last packing."""
     pk = getattr(model, '_packed', None)
-    if pk is None or (need_bwd and pk.wbwd is None):
+    versions = _param_versions(model)
+    if pk is None or pk.versions != versions or (need_bwd and pk.wbwd is None):
         pk = Packed(model, need_bwd)
+        pk.versions = versions
         model._packed = pk
     return pk
 

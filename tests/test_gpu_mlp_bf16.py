@@ -229,3 +229,29 @@ def test_nerf_end_to_end_bf16(golden, tag):
             assert abs(float(v.grad.norm() / ref.norm()) - 1) < 3e-2, k
         else:
             assert abs(float(v.grad.norm()) - float(fx['gnorm_' + k])) < 3e-2 * float(fx['gnorm_' + k]), k
+
+
+def test_packed_weights_follow_parameter_updates():
+    """The packed bf16 streams are rebuilt after any in-place parameter write (optimizer step, load_state_dict):
+    no stale weights, without the caller announcing the change."""
+    from nerf_amd import mlp_bf16
+    from nerf_amd.model import MipNeRF
+    cfg = make_cfg(hidden=64, num_samples=16, max_deg=4)
+    m = MipNeRF(cfg).cuda()
+    rays = make_rays(8, 1)
+    t = O.stratified_t(rays.near, rays.far, 16, None).cuda()
+    viewf = mlp_bf16.view_frag(rays.viewdirs.cuda(), 0, 4)
+    r = O.Rays(*(getattr(rays, f).cuda() for f in ('origins', 'directions', 'viewdirs', 'radii', 'lossmult', 'near', 'far')))
+    with torch.no_grad():
+        a = mlp_bf16.query_nerf(m, t, r, viewf, 16)[0].clone()
+        pk = m._packed
+        assert mlp_bf16.packed_for(m, need_bwd=False) is pk                      # unchanged weights: cached
+        m.load_state_dict({k: v.cuda() for k, v in O.init_params(cfg, seed=9).items()}, strict=False)
+        b = mlp_bf16.query_nerf(m, t, r, viewf, 16)[0].clone()
+        assert m._packed is not pk and not torch.equal(a, b)
+        torch.optim.SGD(m.parameters(), lr=0.1)                                   # an in-place step by hand
+        for q in m.parameters():
+            if q.requires_grad:
+                q.add_(0.05)
+        c = mlp_bf16.query_nerf(m, t, r, viewf, 16)[0]
+        assert not torch.equal(b, c)
