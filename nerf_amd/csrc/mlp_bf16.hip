@@ -183,7 +183,7 @@ struct MlpFwdArgs {
 // 4*blockIdx + (w >> 1) and loads pieces w, w+8, ... of every stage.
 constexpr int kWaves = 8;
 #ifndef NERF_LDS_AHEAD
-#define NERF_LDS_AHEAD 6
+#define NERF_LDS_AHEAD 3
 #endif
 constexpr int kLdsAhead = NERF_LDS_AHEAD;     // weight pieces in flight LDS -> registers per wave
 
