@@ -66,11 +66,23 @@ int nerf_sar_raygen(const float* az, const float* el, int64_t n_rays, float* ray
                     void* stream);
 
 /* Pinhole-camera rays for ray ids (flat (camera, row, col) index; ids NULL = 0..n-1): origins, directions,
- * viewdirs [n,3], radii, lossmult (= 1), near, far [n].  cam_to_world is [n_cams, 3, 4] row-major fp32.  Ids are
- * not range-checked against n_cams * h * w: the caller draws them.     reference: dataloader.py:103-138 */
+ * viewdirs [n,3], radii, lossmult (= 1), near, far [n].  cam_to_world is [n_cams, 3, 4] row-major fp32.  An id
+ * outside [0, n_cams * h * w) yields a ray of NaNs.  h >= 3.            reference: dataloader.py:103-138 */
 int nerf_pinhole_rays(const float* cam_to_world, int n_cams, int h, int w, float focal, float near_, float far_,
                       const int64_t* ids, int64_t n, float* origins, float* directions, float* viewdirs,
                       float* radii, float* lossmult, float* near_out, float* far_out, void* stream);
+
+/* Rays to normalised device coordinates: origins shifted to the plane z = -ndc_near, then projected; fp32
+ * arithmetic of float32 arrays with a float32 focal.                     reference: utils.py:66-86 */
+int nerf_convert_to_ndc(const float* origins, const float* directions, int64_t n, float focal, int w, int h,
+                        float ndc_near, float* origins_out, float* directions_out, void* stream);
+
+/* Forward-facing (LLFF) rays for ray ids: pinhole rays converted to NDC (near plane 1), radii from the spacing of
+ * NDC origins along rows and columns, viewdirs = unnormalised world directions; same argument meaning as
+ * nerf_pinhole_rays.  h, w >= 3.                                         reference: dataloader.py:437-460 */
+int nerf_ndc_rays(const float* cam_to_world, int n_cams, int h, int w, float focal, float near_, float far_,
+                  const int64_t* ids, int64_t n, float* origins, float* directions, float* viewdirs,
+                  float* radii, float* lossmult, float* near_out, float* far_out, void* stream);
 
 /* ---- (c) hierarchical resampling ------------------------------------------------------ */
 

@@ -32,6 +32,8 @@ _SIGS = {
     'nerf_pe_encode': (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P]),
     'nerf_sar_raygen': (c_int, [_P, _P, c_int64, _P, _P, _P]),
     'nerf_pinhole_rays': (c_int, [_P, c_int, c_int, c_int, c_float, c_float, c_float, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'nerf_convert_to_ndc': (c_int, [_P, _P, c_int64, c_float, c_int, c_int, c_float, _P, _P, _P]),
+    'nerf_ndc_rays': (c_int, [_P, c_int, c_int, c_int, c_float, c_float, c_float, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     'nerf_resample': (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_float, c_int, _P, _P, _P, _P]),
     'nerf_invert_cdf': (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     'nerf_composite_fwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, POINTER(NerfActivation),

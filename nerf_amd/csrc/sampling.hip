@@ -335,6 +335,12 @@ __global__ void pinhole_rays_kernel(const float* __restrict__ c2w, int n_cams, i
     const int col = (int)(id % w);
     const int row = (int)((id / w) % h);
     const int64_t cam = id / ((int64_t)w * h);
+    if (id < 0 || cam >= n_cams) {  // a pixel id outside the image stack: mark the ray, read nothing
+        const float nan = __builtin_nanf("");
+        for (int k = 0; k < 3; ++k) origins[i * 3 + k] = directions[i * 3 + k] = viewdirs[i * 3 + k] = nan;
+        radii[i] = lossmult[i] = near_o[i] = far_o[i] = nan;
+        return;
+    }
     const float* R = c2w + cam * 12;
     float d[3], e[3];
     pinhole_dir(R, (float)col, (float)row, h, w, focal, d);
@@ -368,6 +374,125 @@ extern "C" int nerf_pinhole_rays(const float* cam_to_world, int n_cams, int h, i
     hipLaunchKernelGGL(pinhole_rays_kernel, dim3(nerf_blocks(n, 256)), dim3(256), 0, nerf_stream(stream), cam_to_world,
                        n_cams, h, w, focal, near_, far_, ids, n, origins, directions, viewdirs, radii, lossmult, near_out,
                        far_out);
+    return nerf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Normalised device coordinates (utils.py:66-86) in fp32, the arithmetic of float32 arrays with a float32
+// focal: cw = -((2 focal)/w) and ch = -((2 focal)/h) are rounded to fp32 before use.
+struct NdcCoef { float cw, ch, near_, two_near, m_two_near; };
+
+__device__ __forceinline__ void ndc_point(const float* __restrict__ o_in, const float (&d)[3], const NdcCoef& c,
+                                          float (&o)[3], float (&dd)[3]) {
+    const float eps = 1e-15f;
+    const float t = -(c.near_ + o_in[2]) / (d[2] + eps);
+    const float ox = o_in[0] + t * d[0], oy = o_in[1] + t * d[1], oz = o_in[2] + t * d[2];
+    const float ze = oz + eps, dze = d[2] + eps;
+    o[0] = c.cw * (ox / ze);
+    o[1] = c.ch * (oy / ze);
+    o[2] = 1.0f + c.two_near / ze;
+    dd[0] = c.cw * (d[0] / dze - ox / ze);
+    dd[1] = c.ch * (d[1] / dze - oy / ze);
+    dd[2] = c.m_two_near / ze;
+}
+
+static NdcCoef ndc_coef(float focal, int w, int h, float near_) {
+    const float f2 = 2.0f * focal;
+    return NdcCoef{-(f2 / (float)w), -(f2 / (float)h), near_, (float)(2.0 * (double)near_),
+                   (float)(-2.0 * (double)near_)};
+}
+
+__global__ void convert_to_ndc_kernel(const float* __restrict__ origins, const float* __restrict__ directions,
+                                      int64_t n, NdcCoef c, float* __restrict__ o_out, float* __restrict__ d_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float o_in[3], d[3], o[3], dd[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o_in[k] = origins[i * 3 + k];
+        d[k] = directions[i * 3 + k];
+    }
+    ndc_point(o_in, d, c, o, dd);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o_out[i * 3 + k] = o[k];
+        d_out[i * 3 + k] = dd[k];
+    }
+}
+
+extern "C" int nerf_convert_to_ndc(const float* origins, const float* directions, int64_t n, float focal, int w, int h,
+                                   float ndc_near, float* origins_out, float* directions_out, void* stream) {
+    if (n == 0) return NERF_OK;
+    NERF_REQUIRE(origins && directions && origins_out && directions_out && n > 0 && w > 0 && h > 0);
+    hipLaunchKernelGGL(convert_to_ndc_kernel, dim3(nerf_blocks(n, 256)), dim3(256), 0, nerf_stream(stream), origins,
+                       directions, n, ndc_coef(focal, w, h, ndc_near), origins_out, directions_out);
+    return nerf_launch_status();
+}
+
+// Forward-facing (LLFF) rays on the device (dataloader.py:437-460): pinhole ray -> NDC origin and direction;
+// radius from the spacing of NDC origins to the next row and the next column (last row / column reuse the
+// spacing one step in, as upstream's `[-2:-1]` append does); view direction = the unnormalised world direction.
+__global__ void ndc_rays_kernel(const float* __restrict__ c2w, int n_cams, int h, int w, float focal, NdcCoef c,
+                                float near_, float far_, const int64_t* __restrict__ ids, int64_t n,
+                                float* __restrict__ origins, float* __restrict__ directions,
+                                float* __restrict__ viewdirs, float* __restrict__ radii, float* __restrict__ lossmult,
+                                float* __restrict__ near_o, float* __restrict__ far_o) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t id = ids ? ids[i] : i;
+    const int col = (int)(id % w);
+    const int row = (int)((id / w) % h);
+    const int64_t cam = id / ((int64_t)w * h);
+    if (id < 0 || cam >= n_cams) {
+        const float nan = __builtin_nanf("");
+        for (int k = 0; k < 3; ++k) origins[i * 3 + k] = directions[i * 3 + k] = viewdirs[i * 3 + k] = nan;
+        radii[i] = lossmult[i] = near_o[i] = far_o[i] = nan;
+        return;
+    }
+    const float* R = c2w + cam * 12;
+    const float pos[3] = {R[3], R[7], R[11]};
+    auto origin_at = [&](int r, int cc, float (&o)[3]) {
+        float d[3], dd[3];
+        pinhole_dir(R, (float)cc, (float)r, h, w, focal, d);
+        ndc_point(pos, d, c, o, dd);
+    };
+    auto dist = [](const float (&a)[3], const float (&b)[3]) {
+        const float q0 = a[0] - b[0], q1 = a[1] - b[1], q2 = a[2] - b[2];
+        return sqrtf((q0 * q0 + q1 * q1) + q2 * q2);
+    };
+    float d[3], o[3], dd[3];
+    pinhole_dir(R, (float)col, (float)row, h, w, focal, d);
+    ndc_point(pos, d, c, o, dd);
+    const int r0 = row < h - 1 ? row : h - 3;
+    const int c0 = col < w - 1 ? col : w - 3;
+    float a[3], b[3];
+    origin_at(r0, col, a);
+    origin_at(r0 + 1, col, b);
+    const float dx = dist(a, b);
+    origin_at(row, c0, a);
+    origin_at(row, c0 + 1, b);
+    const float dy = dist(a, b);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        origins[i * 3 + k] = o[k];
+        directions[i * 3 + k] = dd[k];
+        viewdirs[i * 3 + k] = d[k];
+    }
+    radii[i] = (float)((double)((0.5f * (dx + dy)) * 2.0f) / sqrt(12.0));
+    lossmult[i] = 1.0f;
+    near_o[i] = near_;
+    far_o[i] = far_;
+}
+
+extern "C" int nerf_ndc_rays(const float* cam_to_world, int n_cams, int h, int w, float focal, float near_, float far_,
+                             const int64_t* ids, int64_t n, float* origins, float* directions, float* viewdirs,
+                             float* radii, float* lossmult, float* near_out, float* far_out, void* stream) {
+    if (n == 0) return NERF_OK;
+    NERF_REQUIRE(cam_to_world && origins && directions && viewdirs && radii && lossmult && near_out && far_out &&
+                 n > 0 && n_cams > 0 && h >= 3 && w >= 3 && focal > 0.f);
+    hipLaunchKernelGGL(ndc_rays_kernel, dim3(nerf_blocks(n, 256)), dim3(256), 0, nerf_stream(stream), cam_to_world,
+                       n_cams, h, w, focal, ndc_coef(focal, w, h, 1.0f), near_, far_, ids, n, origins, directions,
+                       viewdirs, radii, lossmult, near_out, far_out);
     return nerf_launch_status();
 }
 

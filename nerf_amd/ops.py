@@ -68,10 +68,12 @@ def sar_raygen(az, el):
     return ray_d, ray_p
 
 
-def pinhole_rays(cam_to_world, h, w, focal, near, far, ids=None):
+def pinhole_rays(cam_to_world, h, w, focal, near, far, ids=None, ndc=False):
     """Rays of a pinhole camera model generated on the device (dataloader.py:103-138) -> utils.Rays of `[n, .]`
-    tensors.  cam_to_world: [C, 3 or 4, 4]; ids: flat (camera, row, col) indices (int64) or None for every pixel."""
+    tensors.  cam_to_world: [C, 3 or 4, 4]; ids: flat (camera, row, col) indices (int64) or None for every pixel.
+    `ndc=True` gives the forward-facing variant in normalised device coordinates (dataloader.py:437-460)."""
     from .utils import Rays
+    entry = lib().nerf_ndc_rays if ndc else lib().nerf_pinhole_rays
     c2w = f32c(cam_to_world[:, :3, :4])
     n_cams = c2w.shape[0]
     if ids is None:
@@ -82,9 +84,24 @@ def pinhole_rays(cam_to_world, h, w, focal, near, far, ids=None):
     dev = c2w.device
     o, d, v = (torch.empty(n, 3, device=dev, dtype=torch.float32) for _ in range(3))
     r, lm, ne, fa = (torch.empty(n, 1, device=dev, dtype=torch.float32) for _ in range(4))
-    check(lib().nerf_pinhole_rays(ptr(c2w), n_cams, h, w, float(focal), float(near), float(far), idp, n, ptr(o), ptr(d),
-                                  ptr(v), ptr(r), ptr(lm), ptr(ne), ptr(fa), stream()))
+    check(entry(ptr(c2w), n_cams, h, w, float(focal), float(near), float(far), idp, n, ptr(o), ptr(d), ptr(v), ptr(r),
+                ptr(lm), ptr(ne), ptr(fa), stream()))
     return Rays(o, d, v, r, lm, ne, fa)
+
+
+def ndc_rays(cam_to_world, h, w, focal, near, far, ids=None):
+    return pinhole_rays(cam_to_world, h, w, focal, near, far, ids, ndc=True)
+
+
+def convert_to_ndc(origins, directions, focal, w, h, near=1.):
+    """utils.py:66-86 on device tensors `[..., 3]` -> (origins, directions) in normalised device coordinates."""
+    o, d = f32c(origins), f32c(directions)
+    assert o.shape == d.shape and o.shape[-1] == 3
+    n = o.numel() // 3
+    oo, dd = torch.empty_like(o), torch.empty_like(d)
+    check(lib().nerf_convert_to_ndc(ptr(o), ptr(d), n, float(focal), int(w), int(h), float(near), ptr(oo), ptr(dd),
+                                    stream()))
+    return oo, dd
 
 
 def resample(t_vals, weights, n_out, resample_padding, u_rand=None, blur=True, return_idx=False, return_cdf=False):

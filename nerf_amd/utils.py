@@ -21,6 +21,11 @@ def namedtuple_map(fn, tup):
     return type(tup)(*map(fn, tup))
 
 
+def convert_to_ndc(origins, directions, focal, w, h, near=1.):
+    """Convert a set of rays to NDC coordinates (utils.py:66-86); device tensors instead of NumPy arrays."""
+    return ops.convert_to_ndc(origins, directions, focal, w, h, near)
+
+
 def _flat(x, last):
     return x.reshape(-1, last)
 

@@ -24,6 +24,7 @@ import torch.nn as nn
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+_ARGS = sys.argv[1:]
 sys.argv = ['x']
 sys.path.insert(0, '/root/reference')
 
@@ -416,7 +417,35 @@ def gen_misc():
          az=az[:, 0], el=el[:, 0], ray_d=ray_d[0], ray_p=ray_p.T[0])
 
 
+def gen_ndc():
+    """`convert_to_ndc` (utils.py:66-86) on float32 pinhole rays with a float32 focal (the LLFF loader's types,
+    dataloader.py:338,440), and `to8b` (utils.py:619-623)."""
+    rng = np.random.default_rng(21)
+    n_cams, h, w = 2, 7, 9
+    focal = np.float32(11.3)
+    c2w = np.zeros((n_cams, 3, 4), np.float32)
+    for c in range(n_cams):
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        c2w[c, :, :3] = q.astype(np.float32)
+        c2w[c, :, 3] = (rng.standard_normal(3) * 0.3 + [0, 0, 1.5]).astype(np.float32)
+    x, y = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32), indexing='xy')
+    cam = np.stack([(x - w * 0.5 + 0.5) / focal, -(y - h * 0.5 + 0.5) / focal, -np.ones_like(x)], axis=-1)
+    directions = (cam[None, ..., None, :] * c2w[:, None, None, :3, :3]).sum(axis=-1)
+    origins = np.broadcast_to(c2w[:, None, None, :3, -1], directions.shape)
+    assert directions.dtype == np.float32
+    o_ndc, d_ndc = R_utils.convert_to_ndc(origins, directions, focal, w, h)
+    assert o_ndc.dtype == np.float32 and d_ndc.dtype == np.float32
+    o_ndc2, d_ndc2 = R_utils.convert_to_ndc(origins, directions, focal, w, h, near=0.5)
+    img = rng.standard_normal((5, 6, 3)).astype(np.float32) * 0.7 + 0.5
+    save('ndc', c2w=c2w, h=h, w=w, focal=focal, origins=np.ascontiguousarray(origins), directions=directions,
+         o_ndc=o_ndc, d_ndc=d_ndc, o_ndc_near05=o_ndc2, d_ndc_near05=d_ndc2, img=img, img8=R_utils.to8b(img))
+
+
 if __name__ == '__main__':
+    if _ARGS == ['ndc']:
+        gen_ndc()
+        sys.exit(0)
+    gen_ndc()
     gen_sample()
     gen_posenc()
     gen_resample()

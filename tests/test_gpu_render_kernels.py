@@ -295,3 +295,72 @@ def test_pinhole_rays_match_oracle():
     for name, a, b in zip(sub._fields, sub, ref):
         assert torch.equal(a.cpu(), b[ids]), name
     assert ops.pinhole_rays(c2w.cuda(), h, w, focal, 2.0, 6.0, ids=ids[:0].cuda()).origins.shape == (0, 3)
+
+
+def test_convert_to_ndc_matches_golden():
+    """utils.convert_to_ndc against the reference's output on float32 rays (bit-exact: same fp32 expression order)."""
+    import os
+    from nerf_amd import utils as U
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ndc.npz'))
+    o = torch.tensor(g['origins']).cuda()
+    d = torch.tensor(g['directions']).cuda()
+    for near, ko, kd in ((1., 'o_ndc', 'd_ndc'), (0.5, 'o_ndc_near05', 'd_ndc_near05')):
+        oo, dd = U.convert_to_ndc(o, d, float(g['focal']), int(g['w']), int(g['h']), near)
+        assert oo.shape == o.shape
+        np.testing.assert_allclose(oo.cpu().numpy(), g[ko], rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(dd.cpu().numpy(), g[kd], rtol=2e-6, atol=1e-7)
+    from nerf_amd.model import to8b
+    assert np.array_equal(to8b(g['img']), g['img8'])
+
+
+def test_ndc_rays_match_oracle():
+    """nerf_ndc_rays against the NumPy restatement of the forward-facing loader (parity unpinned beyond
+    convert_to_ndc): all pixels, then a shuffled id subset, then ids outside the stack."""
+    from nerf_amd import ops
+    rng = np.random.default_rng(5)
+    C, h, w, focal = 3, 9, 11, 13.7
+    c2w = np.zeros((C, 3, 4), np.float32)
+    for c in range(C):
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        c2w[c, :, :3] = q
+        c2w[c, :, 3] = rng.standard_normal(3) * 0.3 + [0, 0, 1.5]
+    want = O.ndc_rays(c2w, h, w, focal, 0., 1.)
+    got = ops.ndc_rays(torch.tensor(c2w).cuda(), h, w, focal, 0., 1.)
+    for name, a, b in zip(got._fields, got, want):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=3e-5, atol=2e-6, err_msg=name)
+    ids = torch.tensor(rng.permutation(C * h * w)[:100]).cuda()
+    sub = ops.ndc_rays(torch.tensor(c2w).cuda(), h, w, focal, 0., 1., ids)
+    for a, b in zip(sub, got):
+        assert torch.equal(a, b[ids])
+    bad = ops.ndc_rays(torch.tensor(c2w).cuda(), h, w, focal, 0., 1., torch.tensor([C * h * w, -1, 5]).cuda())
+    assert torch.isnan(bad.origins[:2]).all() and torch.equal(bad.origins[2], got.origins[5])
+    bad = ops.pinhole_rays(torch.tensor(c2w).cuda(), h, w, focal, 2., 6., torch.tensor([C * h * w, 7]).cuda())
+    assert torch.isnan(bad.radii[0]).all() and torch.isfinite(bad.radii[1]).all()
+
+
+def test_ray_batches_epoch():
+    """One shuffled epoch visits every pixel once; rays and pixels of a batch belong to the same ids; two ranks
+    split each batch without overlap."""
+    from nerf_amd import ops
+    from nerf_amd.rays import RayBatches
+    C, h, w = 2, 6, 7
+    c2w = torch.eye(4)[None, :3].repeat(C, 1, 1).cuda()
+    c2w[1, 0, 3] = 0.5
+    imgs = torch.arange(C * h * w * 3, dtype=torch.float32).reshape(C, h, w, 3).cuda()
+    full = ops.pinhole_rays(c2w, h, w, 20., 2., 6.)
+    seen = []
+    batches = RayBatches(c2w, h, w, 20., 2., 6., images=imgs, batch_size=32, seed=3)
+    assert len(batches) == 3
+    for rays, pix in batches:
+        ids = (pix[:, 0] / 3).long()
+        seen.append(ids)
+        assert torch.equal(rays.directions, full.directions[ids])
+        assert torch.equal(rays.origins, full.origins[ids])
+    seen = torch.cat(seen)
+    assert seen.numel() == C * h * w and torch.equal(seen.sort().values, torch.arange(C * h * w, device='cuda'))
+    halves = [list(RayBatches(c2w, h, w, 20., 2., 6., images=imgs, batch_size=32, seed=3, rank=r, world_size=2))
+              for r in range(2)]
+    both = torch.cat([p[:, 0] for r in range(2) for _, p in halves[r]])
+    assert both.numel() == C * h * w and both.unique().numel() == C * h * w
+    ordered = list(RayBatches(c2w, h, w, 20., 2., 6., batch_size=50, shuffle=False))
+    assert torch.equal(torch.cat([r.directions for r in ordered]), full.directions)

@@ -5,6 +5,8 @@ outputs (and gradients) the reference itself produced on the same inputs and the
 same pre-drawn random numbers.  Tolerances: exact or ~1e-6 for elementwise stages,
 1e-5 relative for end-to-end quantities (fp32 summation-order noise only).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -189,3 +191,16 @@ def test_pinhole_rays_oracle_properties():
     assert torch.allclose(d[:, 2], -torch.ones(80)) and float(d[0, 0]) == (0 - 5.0 + 0.5) / 12.0
     assert torch.allclose(r, torch.full((80, 1), (1 / 12.0) * 2 / 12 ** 0.5), rtol=1e-6)      # identity pose: dx = 1/focal
     assert bool((ne == 2).all()) and bool((fa == 6).all())
+
+
+def test_convert_to_ndc_oracle_matches_golden():
+    """The NumPy restatement of convert_to_ndc and to8b against the reference's outputs, bit for bit."""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ndc.npz'))
+    for near, ko, kd in ((1., 'o_ndc', 'd_ndc'), (0.5, 'o_ndc_near05', 'd_ndc_near05')):
+        o, d = O.convert_to_ndc(g['origins'], g['directions'], g['focal'][()], int(g['w']), int(g['h']), near)
+        assert o.dtype == np.float32 and np.array_equal(o, g[ko]) and np.array_equal(d, g[kd])
+    assert np.array_equal(O.to8b(g['img']), g['img8'])
+    rays = O.ndc_rays(g['c2w'], int(g['h']), int(g['w']), float(g['focal']), 0., 1.)
+    assert np.array_equal(rays[0].numpy().reshape(g['o_ndc'].shape), g['o_ndc'])
+    assert np.array_equal(rays[2].numpy().reshape(g['directions'].shape), g['directions'])
+    assert (rays[3] > 0).all()
