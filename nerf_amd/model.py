@@ -226,17 +226,22 @@ class MipNeRF(_RenderModule):
     def render_image(self, rays, height, width, chunks=8192):
         """Chunked no-grad render of one image's rays; keeps the last level (model.py:153-175)."""
         length = rays[0].shape[0]
-        rgbs, dists, accs = [], [], []
+        dev = self.device
+        # outputs stay in HBM until the image is complete: one device-to-host copy (and one synchronisation)
+        # per image instead of three per chunk; colours are quantised to 8 bits on the device first
+        rgbs = torch.empty(length, 3, device=dev, dtype=torch.uint8)
+        dists = torch.empty(length, device=dev, dtype=torch.float32)
+        accs = torch.empty(length, device=dev, dtype=torch.float32)
         with torch.no_grad():
             for i in range(0, length, chunks):
-                chunk_rays = namedtuple_map(lambda r: r[i:i + chunks].to(self.device), rays)
+                chunk_rays = namedtuple_map(lambda r: r[i:i + chunks].to(dev, non_blocking=True), rays)
                 rgb, distance, acc = self(chunk_rays)[:3]
-                rgbs.append(rgb[-1].cpu())
-                dists.append(distance[-1].cpu())
-                accs.append(acc[-1].cpu())
-        rgbs = to8b(torch.cat(rgbs, dim=0).reshape(height, width, 3).numpy())
-        dists = torch.cat(dists, dim=0).reshape(height, width).numpy()
-        accs = torch.cat(accs, dim=0).reshape(height, width).numpy()
+                rgbs[i:i + chunks] = (255 * rgb[-1].clamp(0, 1)).to(torch.uint8)      # to8b, utils.py:619-623
+                dists[i:i + chunks] = distance[-1].reshape(-1)
+                accs[i:i + chunks] = acc[-1].reshape(-1)
+        rgbs = rgbs.reshape(height, width, 3).cpu().numpy()
+        dists = dists.reshape(height, width).cpu().numpy()
+        accs = accs.reshape(height, width).cpu().numpy()
         return rgbs, dists, accs
 
     def train_val_get(self, batch, batch_idx, kind='train'):

@@ -59,3 +59,27 @@ def test_c2_forward_does_not_depend_on_chunking_and_stays_in_range():
     assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-6
     assert float(rgb.min()) >= -0.001 * 1.0001 and float(rgb.max()) <= 1.001 * 1.0001
     assert float(dist.min()) >= 2.0 - 1e-5 and float(dist.max()) <= 6.0 + 1e-5
+
+
+def test_render_image_from_pose():
+    """`render_image` (model.py:153-175) on rays generated on the device for a 96 x 128 camera: CPU ray tensors in,
+    8-bit colours out; chunked rendering equals one forward over all rays quantised as `to8b` does; depth and
+    accumulation are the fine level's; the ragged last chunk is handled."""
+    import numpy as np
+    from nerf_amd import ops
+    from nerf_amd.model import MipNeRF, to8b
+    from nerf_amd.utils import namedtuple_map
+    torch.manual_seed(2)
+    m = MipNeRF(cfg(False)).cuda().train()
+    m.randomized = False
+    h, w = 96, 128
+    c2w = torch.eye(4)[None, :3].clone()
+    c2w[0, 2, 3] = 4.0
+    rays = ops.pinhole_rays(c2w.cuda(), h, w, 110.0, 2.0, 6.0)
+    with torch.no_grad():
+        rgb, dist, acc = m(rays)
+    img, depth, alpha = m.render_image(namedtuple_map(lambda t: t.cpu(), rays), h, w, chunks=5000)
+    assert img.dtype == np.uint8 and img.shape == (h, w, 3) and depth.shape == (h, w) and alpha.shape == (h, w)
+    assert np.array_equal(img, to8b(rgb[-1].reshape(h, w, 3).cpu().numpy()))
+    assert np.array_equal(depth, dist[-1].reshape(h, w).cpu().numpy())
+    assert np.array_equal(alpha, acc[-1].reshape(h, w).cpu().numpy())
