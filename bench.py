@@ -186,6 +186,10 @@ def main():
                 roof = {'kernel': dom, 'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS,
                         'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS,
                         'algorithmic_flops_per_launch': r['flops'] / r['calls']}
+                if r['bytes'] > 0:                # the training chain kernels also stream saved activations to HBM
+                    roof['stores'] = {'achieved': r['bytes'] / (r['ms'] * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                      'frac': r['bytes'] / (r['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      'algorithmic_bytes_per_launch': r['bytes'] / r['calls']}
             roof.update(avg_launch_ms=avg_ms, launches_per_step=r['calls'] / args.steps, traffic=pmc_traffic(dom, args.rays) if args.chunk >= args.rays else None)
             out['roofline'] = roof
             mlp_flops = sum(prof[k]['flops'] for k in prof if k.startswith('mlp_'))

@@ -203,7 +203,8 @@ def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False):
         if pk.sar:       # 22: the trunk output once more in frag order, for the LayerNorm backward
             acts.append(torch.empty(nblk * 32 * pk.HT * 128, dtype=torch.uint8, device=dev))
         arr = (c_void_p * len(acts))(*[a.data_ptr() if a is not None else None for a in acts])
-    with profiling.timed('mlp_fwd_kernel', flops=pk.fwd_flops * n_samples):
+    saved = sum(a.numel() for a in acts if a is not None) if save else 0         # bytes the launch writes for the backward pass
+    with profiling.timed('mlp_fwd_kernel', flops=pk.fwd_flops * n_samples, bytes_=float(saved)):
         check(lib().nerf_mlp_fwd(ctypes.byref(pk.dims), _raw(pk.wfwd), ptr(pk.consts), _raw(enc), _raw(view),
                                  n_samples, ray_div, n_rays, arr, ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
                                  ptr(ln_stats), stream()))
@@ -223,7 +224,7 @@ def mlp_backward(pk, acts, n_samples, g_density, g_rgb, raw_rgb, g_angle=None, r
     g_density, g_rgb = f32c(g_density).reshape(-1), f32c(g_rgb).reshape(-1, 3)
     if pk.sar:
         g_angle = f32c(g_angle).reshape(-1, 2)
-    with profiling.timed('mlp_bwd_kernel', flops=pk.bwd_dx_flops * n_samples):
+    with profiling.timed('mlp_bwd_kernel', flops=pk.bwd_dx_flops * n_samples, bytes_=float(sum(d.numel() for d in dys))):
         check(lib().nerf_mlp_bwd(ctypes.byref(pk.dims), _raw(pk.wbwd), ptr(pk.consts), n_samples, ptr(g_density),
                                  ptr(g_rgb), ptr(g_angle), ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
                                  ptr(ln_stats), a_arr, d_arr, stream()))
