@@ -364,3 +364,36 @@ def test_ray_batches_epoch():
     assert both.numel() == C * h * w and both.unique().numel() == C * h * w
     ordered = list(RayBatches(c2w, h, w, 20., 2., 6., batch_size=50, shuffle=False))
     assert torch.equal(torch.cat([r.directions for r in ordered]), full.directions)
+
+
+def test_c_abi_rejects_bad_arguments():
+    """Entry points called straight through ctypes with arguments a careless binding could pass: null pointers,
+    negative or inconsistent sizes, unsupported geometry.  Each returns a negative code and launches nothing."""
+    import ctypes
+    from nerf_amd import _lib, mlp_bf16  # noqa: F401  (mlp_bf16 registers its bindings)
+    L = _lib.lib()
+    buf = torch.zeros(4096, device='cuda')
+    p = ctypes.c_void_p(buf.data_ptr())
+    null = ctypes.c_void_p(None)
+    ERR_ARG, ERR_SIZE = -1, -3
+    assert L.nerf_stratified_t(null, p, null, 8, 4, 0, p, None) == ERR_ARG
+    assert L.nerf_stratified_t(p, p, null, -1, 4, 0, p, None) == ERR_ARG
+    assert L.nerf_stratified_t(p, p, null, 8, 0, 0, p, None) == ERR_ARG           # no samples
+    assert L.nerf_pe_encode(p, 8, 4, 4, 0, p, None) == ERR_ARG                  # max_deg must exceed min_deg
+    assert L.nerf_pe_encode(null, 8, 0, 4, 0, p, None) == ERR_ARG
+    assert L.nerf_pinhole_rays(p, 1, 2, 8, 10.0, 2.0, 6.0, null, 4, p, p, p, p, p, p, p, None) == ERR_ARG     # h < 3
+    assert L.nerf_ndc_rays(p, 1, 8, 2, 10.0, 0.0, 1.0, null, 4, p, p, p, p, p, p, p, None) == ERR_ARG         # w < 3
+    assert L.nerf_pinhole_rays(p, 1, 8, 8, 0.0, 2.0, 6.0, null, 4, p, p, p, p, p, p, p, None) == ERR_ARG      # focal
+    assert L.nerf_convert_to_ndc(p, null, 4, 10.0, 8, 8, 1.0, p, p, None) == ERR_ARG
+    assert L.nerf_sar_raygen(p, null, 4, p, p, None) == ERR_ARG
+    # zero-sized calls are valid no-ops whatever the pointers
+    assert L.nerf_pe_encode(null, 0, 0, 4, 0, null, None) == 0
+    assert L.nerf_convert_to_ndc(null, null, 0, 10.0, 8, 8, 1.0, null, null, None) == 0
+    nw, tn, tk = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert L.nerf_mlp_wgrad_config(256, 256, ctypes.byref(nw), ctypes.byref(tn), ctypes.byref(tk)) == 0
+    assert (nw.value, tn.value, tk.value) == (4, 4, 4)
+    assert L.nerf_mlp_wgrad_config(31, 256, ctypes.byref(nw), ctypes.byref(tn), ctypes.byref(tk)) < 0   # not a multiple of 32
+    assert L.nerf_mlp_wgrad_config(4096, 4096, ctypes.byref(nw), ctypes.byref(tn), ctypes.byref(tk)) == ERR_SIZE
+    assert float(buf.abs().sum()) == 0.0                                        # nothing was written
+    for code in (-1, -2, -3, -4):
+        assert len(L.nerf_error_string(code)) > 0
