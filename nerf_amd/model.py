@@ -300,11 +300,14 @@ class SARNeRF(_RenderModule):
         return mlp.mlp_forward_fp32(self._param_dict(), enc, view_feat[idx], sar=True)
 
     def forward(self, ray_o, pan, tilt, mfilt, _radii, _near, _far, nsam, mpp, az_el=None, t_rand=None,
-                u_rand=None):
+                u_rand=None, rank=0, world_size=1):
         """One pulse (B = 1), as the reference supports (model.py:305-387).  `pan`/`tilt` are unused
         upstream too.  `az_el[c] = (az, el)` optionally supplies chunk c's beam offsets (already scaled
         by the beam sigmas); otherwise they are drawn on the CPU generator like upstream.  `t_rand[c]`
         and `u_rand[c]` optionally supply the sampling draws of chunk c.
+        With `world_size > 1` (torch.distributed initialised) the ray chunks are dealt round-robin to the ranks
+        and the per-level range profiles are SUM-all-reduced ahead of the matched filter: the pulses are those of
+        the one-device loop; distance / acc are those of this rank's last chunk.
         -> pulses [L,1,nsam,2], distance [L,1,R], acc [L,1,R]"""
         cfg = self.config
         dev = self.device
@@ -327,6 +330,8 @@ class SARNeRF(_RenderModule):
             else:                                                                              # model.py:319-320
                 az = torch.randn(R) * SAR_AZ_SIGMA
                 el = torch.randn(R) * SAR_EL_SIGMA
+            if c % world_size != rank:          # another rank's chunk (its beam offsets were drawn above, so that
+                continue                        # every rank walks the same CPU generator sequence)
             ray_d, ray_p = ops.sar_raygen(az.to(dev), el.to(dev))
             bf16 = self._precision() == 'bf16'
             if bf16:
@@ -365,6 +370,12 @@ class SARNeRF(_RenderModule):
                 accs[l] = acc
         mf = mfilt.to(dev)
         outs = []
+        if world_size > 1:
+            from .train import allreduce_sum_shared_loss
+            comp = [allreduce_sum_shared_loss(x, world_size) for x in comp]
+            for l in range(L):                  # a rank that was dealt no chunk still returns tensors
+                if distances[l] is None:
+                    distances[l], accs[l] = torch.zeros(R, device=dev), torch.zeros(R, device=dev)
         for l in range(L):                                                                     # model.py:377-380
             z = torch.view_as_complex(comp[l][None].contiguous())
             z = torch.fft.ifft(mf * torch.fft.fft(z, mf.shape[-1], dim=-1), dim=-1)[..., :nsam]

@@ -80,3 +80,51 @@ def nerf_train_step(model, rays, pixels, optimizer, chunk=8192, world_size=1, gl
         scheduler.step()
     model._weights_changed()
     return total
+
+
+class _AllReduceSumSharedLoss(torch.autograd.Function):
+    """y = sum over ranks of x, for a y that every rank then feeds to the SAME loss: each rank's gradient with
+    respect to its own x is the loss gradient with respect to y, unchanged (no collective in backward); the
+    parameter gradients of the ranks are partial sums and are SUM-all-reduced afterwards."""
+
+    @staticmethod
+    def forward(ctx, x):
+        import torch.distributed as dist
+        y = x.detach().clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def allreduce_sum_shared_loss(x, world_size):
+    return x if world_size <= 1 else _AllReduceSumSharedLoss.apply(x)
+
+
+def sar_train_step(model, batch, optimizer, rank=0, world_size=1, scheduler=None, **draws):
+    """One SAR pulse, ray chunks dealt round-robin to the ranks (model.py:326-375 loops over them on one device).
+
+    The reference ADDS the chunks' range profiles before the matched filter (model.py:371), and within a chunk
+    the last ray written to a range bin wins; dealing whole chunks keeps both rules intact.  Each rank renders
+    its chunks, the per-level profiles are SUM-all-reduced (nsam x 2 floats per level) ahead of the FFT and the
+    per-pulse std, every rank evaluates the same loss, and the weight gradients -- partial sums over each
+    rank's chunks -- are SUM-all-reduced in one flat bucket."""
+    ray_o, pan, tilt, mfilt, radii, near, far, mpp, pulse_data = batch
+    params = [p for p in model.parameters() if p.requires_grad]
+    optimizer.zero_grad(set_to_none=False)
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    pulses = model(ray_o, pan, tilt, mfilt, radii, near, far, pulse_data.shape[1], mpp, rank=rank,
+                   world_size=world_size, **draws)[0]
+    loss, _ = model.loss_function(pulses, pulse_data.to(pulses.device))
+    if loss.requires_grad:              # a rank that was dealt no chunk has nothing to differentiate
+        loss.backward()
+    allreduce_grads(params, world_size)
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    model._weights_changed()
+    return loss.detach()

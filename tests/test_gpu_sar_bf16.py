@@ -140,3 +140,76 @@ def test_sar_end_to_end_bf16(golden):
     go = torch.cat([p[k].grad.reshape(-1) for k, v in m.named_parameters() if not k.endswith('scales')])
     assert bool(torch.isfinite(gk).all())
     assert float((gk * go).sum() / (gk.norm() * go.norm())) > 0.9
+
+
+def _sar_rank_worker(rank, world, port, q):
+    """One rank of the two-process SAR step (both ranks share cuda:0; gloo carries the CUDA tensors)."""
+    import os
+    import numpy as np
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    out = _sar_step(rank, world)
+    q.put((rank,) + tuple(np.ascontiguousarray(x) for x in out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _sar_step(rank, world):
+    import os
+    import numpy as np
+    from tests.conftest import T, cfg_from
+    from nerf_amd.model import SARNeRF
+    from nerf_amd.train import sar_train_step
+    fx = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'sar_e2e_rand.npz'))
+    cfg = cfg_from(fx)
+    cfg.wavelength = 40.0
+    cfg.mlp_precision = 'bf16'
+    m = SARNeRF(cfg).cuda().train()
+    m.load_state_dict(O.init_params(cfg, sar=True, seed=int(fx['wseed'])), strict=False)
+    chunks = cfg.total_num_rays // cfg.rays_per_chunk
+    draws = dict(az_el=[(T(fx[f'az_{c}']), T(fx[f'el_{c}'])) for c in range(chunks)],
+                 t_rand=[T(fx[f't_rand_{c}']).cuda() for c in range(chunks)],
+                 u_rand=[T(fx[f'u_rand_{c}']).cuda() for c in range(chunks)])
+    mfilt = torch.complex(T(fx['mfilt_re']), T(fx['mfilt_im']))
+    batch = (T(fx['ray_o']), None, None, mfilt, T(fx['radii']), T(fx['near']), T(fx['far']), T(fx['mpp']),
+             T(fx['target']))
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)            # keep the weights: gradients are what is compared
+    loss = sar_train_step(m, batch, opt, rank=rank, world_size=world, **draws)
+    grads = torch.cat([p.grad.reshape(-1) for k, p in m.named_parameters() if p.requires_grad])
+    return np.array([float(loss), chunks]), grads.cpu().numpy()
+
+
+def test_sar_chunks_dealt_to_two_ranks_match_one_device():
+    """The SAR step with its ray chunks dealt to two processes (range profiles and gradient bucket all-reduced)
+    gives the loss and the weight gradients of the one-device loop over the same draws."""
+    import socket
+    import torch.multiprocessing as mp
+    one_loss, one_grads = _sar_step(0, 1)
+    assert one_loss[1] >= 2, 'fixture must hold at least two ray chunks'
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sar_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = []
+    try:
+        for _ in range(2):
+            got.append(q.get(timeout=150))
+    finally:
+        for pr in procs:
+            pr.join(30)
+            if pr.is_alive():
+                pr.kill()
+    assert all(pr.exitcode == 0 for pr in procs)
+    import numpy as np
+    for _, loss, grads in got:
+        assert abs(loss[0] - one_loss[0]) <= 1e-4 * abs(one_loss[0])
+        assert np.isfinite(grads).all()
+        # chunk order changes only the order of fp32 sums (profiles, split-K atomics)
+        assert np.linalg.norm(grads - one_grads) <= 2e-3 * np.linalg.norm(one_grads)
+    assert np.array_equal(got[0][2], got[1][2])

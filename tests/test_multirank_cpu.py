@@ -99,3 +99,64 @@ def test_two_rank_gradients_equal_unsharded():
         g0, g1 = torch.from_numpy(g0), torch.from_numpy(g1)
         assert torch.equal(g0, g1)                                      # every rank holds the same reduced bucket
         assert float((g0 - ref.grad).abs().max()) <= 1e-5 * float(ref.grad.abs().max()) + 1e-9
+
+
+def _shared_loss_worker(rank, world, port, q):
+    from nerf_amd.train import allreduce_grads, allreduce_sum_shared_loss
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    theta = torch.nn.Parameter(torch.linspace(-1, 1, 12, dtype=torch.float64).reshape(3, 4))
+    parts = _parts(theta)
+    mine = sum((parts[c] for c in range(len(parts)) if c % world == rank), torch.zeros(5, dtype=torch.float64))
+    y = allreduce_sum_shared_loss(mine, world)
+    loss = _shared_loss(y)
+    if loss.requires_grad:
+        loss.backward()
+    else:
+        theta.grad = torch.zeros_like(theta)
+    allreduce_grads([theta], world)
+    q.put((rank, y.detach().numpy().copy(), theta.grad.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _parts(theta):
+    """Three 'chunks': different differentiable maps of the shared parameters to a 5-vector."""
+    w = torch.cos(torch.arange(20, dtype=torch.float64).reshape(4, 5))
+    return [torch.tanh(theta[c] @ w) * (c + 1) for c in range(3)]
+
+
+def _shared_loss(y):
+    return ((y / y.std()) ** 2 * torch.arange(1, 6)).sum()        # a normalisation over the whole sum, like the pulse std
+
+
+def test_chunk_dealing_with_shared_loss_matches_one_process():
+    """SAR sharding: chunks dealt round-robin, their sum all-reduced ahead of a loss every rank evaluates; the
+    SUM-all-reduced parameter gradients equal those of one process looping over all chunks (3 chunks on 2 ranks,
+    so the shares are unequal)."""
+    world = 2
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shared_loss_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = []
+    try:
+        for _ in range(world):
+            got.append(q.get(timeout=90))
+    finally:
+        for pr in procs:
+            pr.join(30)
+            if pr.is_alive():
+                pr.kill()
+    assert all(pr.exitcode == 0 for pr in procs)
+    theta = torch.nn.Parameter(torch.linspace(-1, 1, 12, dtype=torch.float64).reshape(3, 4))
+    y = sum(_parts(theta))
+    _shared_loss(y).backward()
+    for _, yy, g in got:
+        assert float((torch.from_numpy(yy) - y.detach()).abs().max()) < 1e-12
+        assert float((torch.from_numpy(g) - theta.grad).abs().max()) <= 1e-9 * float(theta.grad.abs().max())
