@@ -98,6 +98,9 @@ def main():
     ap.add_argument('--chunk', type=int, default=65536, help='rays per forward/backward chunk')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rehearse-one-gpu', action='store_true',
+                    help='N>1 ranks all on cuda:0 over gloo: a rehearsal of the multi-rank code path on a one-GPU box '
+                         '(its numbers mean nothing)')
     ap.add_argument('--workload', default='c3', choices=['c3', 'c2'],
                     help="c3 (default, the headline metric): full train step; c2: forward-only render (use --rays 1048576)")
     args = ap.parse_args()
@@ -107,12 +110,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the render path has no CPU fallback)')
+    if args.rehearse_one_gpu:
+        import faulthandler
+        faulthandler.dump_traceback_later(60, exit=True)        # a rehearsal that hangs says where
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from nerf_amd import profiling
     from nerf_amd.model import MipNeRF

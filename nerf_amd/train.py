@@ -38,10 +38,22 @@ def allreduce_grads(params, world_size):
     """SUM-all-reduce of the flattened gradient bucket (RCCL on GPUs, gloo on CPU)."""
     if world_size <= 1:
         return
-    import torch.distributed as dist
     flat = flat_grads(params)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    _all_reduce_sum(flat)
     scatter_flat_grads(params, flat)
+
+
+def _all_reduce_sum(t):
+    """In-place SUM all-reduce.  RCCL reduces device buffers directly; under gloo (CPU rehearsals of the multi-rank
+    path) a device tensor is staged through host memory: gloo's own device path was seen to hang on a 2.4 MB
+    bucket with two ranks on one GPU."""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend() == 'gloo':
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
 def shard_range(n, rank, world_size):
@@ -89,9 +101,8 @@ class _AllReduceSumSharedLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        import torch.distributed as dist
         y = x.detach().clone()
-        dist.all_reduce(y, op=dist.ReduceOp.SUM)
+        _all_reduce_sum(y)
         return y
 
     @staticmethod
