@@ -27,7 +27,8 @@ SAR_EL_SIGMA = 0.09599310885968812      # model.py:320
 
 
 def to8b(img):
-    return (255 * np.clip(img, 0, 1)).astype(np.uint8)
+    """utils.py:619-623 (NaN -> 0, +-inf -> the clip bounds)."""
+    return (255 * np.clip(np.nan_to_num(img), 0, 1)).astype(np.uint8)
 
 
 def _xavier_init(model):
@@ -236,7 +237,7 @@ class MipNeRF(_RenderModule):
             for i in range(0, length, chunks):
                 chunk_rays = namedtuple_map(lambda r: r[i:i + chunks].to(dev, non_blocking=True), rays)
                 rgb, distance, acc = self(chunk_rays)[:3]
-                rgbs[i:i + chunks] = (255 * rgb[-1].clamp(0, 1)).to(torch.uint8)      # to8b, utils.py:619-623
+                rgbs[i:i + chunks] = (255 * torch.nan_to_num(rgb[-1]).clamp(0, 1)).to(torch.uint8)      # to8b, utils.py:619-623
                 dists[i:i + chunks] = distance[-1].reshape(-1)
                 accs[i:i + chunks] = acc[-1].reshape(-1)
         rgbs = rgbs.reshape(height, width, 3).cpu().numpy()

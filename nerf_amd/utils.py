@@ -26,6 +26,18 @@ def convert_to_ndc(origins, directions, focal, w, h, near=1.):
     return ops.convert_to_ndc(origins, directions, focal, w, h, near)
 
 
+def to8b(img):
+    """utils.py:619-623 on a NumPy image (any leading dims)."""
+    import numpy as np
+    return (255 * np.clip(np.nan_to_num(np.asarray(img)), 0, 1)).astype(np.uint8)
+
+
+def to_float(img):
+    """utils.py:626-630."""
+    import numpy as np
+    return (np.asarray(img) / 255.).astype(np.float32)
+
+
 def _flat(x, last):
     return x.reshape(-1, last)
 

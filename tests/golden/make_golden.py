@@ -437,6 +437,7 @@ def gen_ndc():
     assert o_ndc.dtype == np.float32 and d_ndc.dtype == np.float32
     o_ndc2, d_ndc2 = R_utils.convert_to_ndc(origins, directions, focal, w, h, near=0.5)
     img = rng.standard_normal((5, 6, 3)).astype(np.float32) * 0.7 + 0.5
+    img[0, 0, 0], img[0, 1, 1], img[1, 0, 2] = np.nan, np.inf, -np.inf          # to8b maps them to 0, 255, 0
     save('ndc', c2w=c2w, h=h, w=w, focal=focal, origins=np.ascontiguousarray(origins), directions=directions,
          o_ndc=o_ndc, d_ndc=d_ndc, o_ndc_near05=o_ndc2, d_ndc_near05=d_ndc2, img=img, img8=R_utils.to8b(img))
 

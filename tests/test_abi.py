@@ -41,3 +41,22 @@ def test_cpu_tensors_are_refused():
     from nerf_amd import ops
     with pytest.raises(RuntimeError):
         ops.stratified_t(torch.zeros(3, 1), torch.ones(3, 1), 4)
+
+
+def test_python_surface_has_the_reference_names():
+    """Every name the reference's model.py takes from `utils` / `util_modules` (model.py:8-11), and the model
+    classes its scripts take from `model` (train.py:7, train_sar.py:14), exists here under the same name."""
+    import nerf_amd.model as M
+    import nerf_amd.util_modules as UM
+    import nerf_amd.utils as U
+    for n in ('sample_along_rays', 'resample_along_rays', 'volumetric_rendering', 'namedtuple_map', 'to8b',
+              'volumetric_scattering', 'cast_rays', 'sorted_piecewise_constant_pdf', 'convert_to_ndc', 'Rays', 'to_float'):
+        assert callable(getattr(U, n)), n
+    for n in ('PositionalEncoding', 'MipLRDecay', 'NeRFLoss', 'SARNeRFLoss', 'mse_to_psnr'):
+        assert callable(getattr(UM, n)), n
+    for cls, methods in ((M.MipNeRF, ('forward', 'render_image', 'training_step', 'validation_step', 'train_val_get',
+                                      'configure_optimizers')),
+                         (M.SARNeRF, ('forward', 'training_step', 'validation_step', 'train_val_get',
+                                      'configure_optimizers'))):
+        for name in methods:
+            assert callable(getattr(cls, name)), (cls.__name__, name)
