@@ -74,7 +74,7 @@ __device__ __forceinline__ void step(f32x16& acc, bf16x8 (&a)[D], unsigned addr,
         step<KS, D, ks + 1>(acc, a, addr, b);
     }
 }
-template <bool STORES, bool WSTREAM>
+template <bool STORES, bool WSTREAM, int EPI>
 __global__ __launch_bounds__(512, 2) void chain_model(bf16x8* __restrict__ dst, long per_layer, const char* __restrict__ wts, float* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -96,9 +96,18 @@ __global__ __launch_bounds__(512, 2) void chain_model(bf16x8* __restrict__ dst, 
     };
     int cur = 0;
     if (WSTREAM) { fetch(0); fetch(1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    bf16x8 o[16];
+    for (int k2 = 0; k2 < 16; ++k2) o[k2] = b[k2];
+    f32x16 prev = acc;
+    const float* bias = (const float*)smem;
+#pragma unroll
     for (int l = 0; l < kLayers; ++l) {
         bf16x8* base = dst + l * per_layer;
         if (WSTREAM) src = wts + l * 4 * 32768;
+        if (EPI) {      // this layer's inputs are the previous layer's outputs
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) b[k2] = o[k2];
+        }
 #pragma unroll
         for (int st = 0; st < kNT / 2; ++st) {
             if (WSTREAM) fetch((cur + 2) % 3);
@@ -107,10 +116,35 @@ __global__ __launch_bounds__(512, 2) void chain_model(bf16x8* __restrict__ dst, 
                 const int nt = st * 2 + j;
                 const unsigned addr = (unsigned)(size_t)(ring + cur * 32768 + j * 16384 + lane * 16);
                 bf16x8 a[3];
+                if (EPI) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                }
                 issue<0, 3>(a, addr);
                 step<16, 3, 0>(acc, a, addr, b);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], b[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[2], b[3], acc, 0, 0, 0);
+                if (!EPI) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], b[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[2], b[3], acc, 0, 0, 0);
+                } else {    // finish the previous tile: bias, bf16, ReLU -> two operand pieces of the next layer
+                    const int pt = (nt + kNT - 1) % kNT;
+                    f32x16 v;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 bb = *(const float4*)(bias + pt * 32 + 8 * g + 4 * (lane >> 5));
+                        v[4 * g + 0] = prev[4 * g + 0] + bb.x;
+                        v[4 * g + 1] = prev[4 * g + 1] + bb.y;
+                        v[4 * g + 2] = prev[4 * g + 2] + bb.z;
+                        v[4 * g + 3] = prev[4 * g + 3] + bb.w;
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        bf16x8 q;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) q[j] = (__bf16)fmaxf(v[8 * s2 + j], 0.f);
+                        o[2 * pt + s2] = q;
+                    }
+                    prev = acc;
+                }
                 if (STORES) {
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
@@ -127,27 +161,27 @@ __global__ __launch_bounds__(512, 2) void chain_model(bf16x8* __restrict__ dst, 
             cur = (cur + 1) % 3;
         }
     }
-    if (acc[0] == 123.456f) sink[0] = acc[1];
+    if (acc[0] == 123.456f) sink[0] = acc[1] + (float)o[3][1] + prev[2];
 }
-template <bool STORES, bool WSTREAM>
+template <bool STORES, bool WSTREAM, int EPI>
 void run_model(bf16x8* dst, long per_layer, int nwg, const char* wts, float* sink) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const int lds = 96 * 1024;
-    hipFuncSetAttribute((const void*)chain_model<STORES, WSTREAM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    for (int it = 0; it < 2; ++it) hipLaunchKernelGGL((chain_model<STORES, WSTREAM>), dim3(nwg), dim3(512), lds, 0, dst, per_layer, wts, sink);
+    hipFuncSetAttribute((const void*)chain_model<STORES, WSTREAM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    for (int it = 0; it < 2; ++it) hipLaunchKernelGGL((chain_model<STORES, WSTREAM, EPI>), dim3(nwg), dim3(512), lds, 0, dst, per_layer, wts, sink);
     hipEventRecord(e0);
     const int reps = 5;
-    for (int it = 0; it < reps; ++it) hipLaunchKernelGGL((chain_model<STORES, WSTREAM>), dim3(nwg), dim3(512), lds, 0, dst, per_layer, wts, sink);
+    for (int it = 0; it < reps; ++it) hipLaunchKernelGGL((chain_model<STORES, WSTREAM, EPI>), dim3(nwg), dim3(512), lds, 0, dst, per_layer, wts, sink);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     ms /= reps;
     const double bytes = STORES ? (double)nwg * 8 * kLayers * kNT * 2 * 1024 : 0.0;
-    const double flops = (double)nwg * 8 * kLayers * kNT * 18 * 2.0 * 32 * 32 * 16;
-    printf("model stores %d wstream %d: %.3f ms  %.2f TB/s  %.0f TFLOP/s\n", (int)STORES, (int)WSTREAM, ms, bytes / ms / 1e9, flops / ms / 1e9);
+    const double flops = (double)nwg * 8 * kLayers * kNT * (EPI ? 16 : 18) * 2.0 * 32 * 32 * 16;
+    printf("model epi %d stores %d wstream %d: %.3f ms  %.2f TB/s  %.0f TFLOP/s\n", EPI, (int)STORES, (int)WSTREAM, ms, bytes / ms / 1e9, flops / ms / 1e9);
 }
 
 int main() {
@@ -167,10 +201,11 @@ int main() {
     char* wts;
     hipMalloc(&wts, (kLayers * 4 + 4) * 32768);
     hipMemset(wts, 0, (kLayers * 4 + 4) * 32768);
-    run_model<false, false>(dst, per_layer, nwg, wts, sink);
-    run_model<true, false>(dst, per_layer, nwg, wts, sink);
-    run_model<false, true>(dst, per_layer, nwg, wts, sink);
-    run_model<true, true>(dst, per_layer, nwg, wts, sink);
+    run_model<false, false, 0>(dst, per_layer, nwg, wts, sink);
+    run_model<true, false, 0>(dst, per_layer, nwg, wts, sink);
+    run_model<false, true, 0>(dst, per_layer, nwg, wts, sink);
+    run_model<true, true, 0>(dst, per_layer, nwg, wts, sink);
+    run_model<false, true, 1>(dst, per_layer, nwg, wts, sink);
     hipFree(wts);
     hipFree(dst);
     hipFree(sink);
