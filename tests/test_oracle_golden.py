@@ -115,7 +115,7 @@ def _rays(fx):
     return O.Rays(*(T(fx['ray_' + k]) for k in ('origins', 'directions', 'viewdirs', 'radii', 'lossmult', 'near', 'far')))
 
 
-@pytest.mark.parametrize('tag', ['small', 'small_det', 'c1', 'c3'])
+@pytest.mark.parametrize('tag', ['small', 'small_det', 'small_noview', 'c1', 'c3'])
 def test_nerf_end_to_end(golden, tag):
     fx = golden('nerf_e2e_' + tag)
     cfg = cfg_from(fx)
