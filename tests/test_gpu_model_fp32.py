@@ -182,3 +182,29 @@ def test_training_step_runs_and_descends(golden):
     a = m(rays)[0]
     b = m(rays)[0]
     assert torch.equal(a, b)
+
+
+def test_density_noise_vs_oracle(golden):
+    """`density_noise` (model.py:137-138: raw_density += noise * U(0,1) when randomized) with the draws supplied,
+    against the oracle fed the same draws."""
+    fx = golden('nerf_e2e_small')
+    cfg = cfg_from(fx)
+    cfg.density_noise = 0.7
+    levels = [int(x) for x in fx['levels']]
+    rays = _rays(fx)
+    n = rays.origins.shape[0]
+    g = torch.Generator().manual_seed(4)
+    noise = {l: torch.rand(n, S, 1, generator=g) for l, S in enumerate(levels)}
+    t_rand, u_rand = T(fx['t_rand']), {l: T(fx[f'u_rand_{l}']) for l in range(1, len(levels))}
+    p = O.init_params(cfg, seed=int(fx['wseed']))
+    ref = O.nerf_render(p, O.Rays(*(T(fx['ray_' + k]) for k in ('origins', 'directions', 'viewdirs', 'radii', 'lossmult', 'near', 'far'))),
+                        cfg, levels, t_rand, u_rand, noise)
+    quiet = O.nerf_render(p, O.Rays(*(T(fx['ray_' + k]) for k in ('origins', 'directions', 'viewdirs', 'radii', 'lossmult', 'near', 'far'))),
+                          cfg, levels, t_rand, u_rand, None)
+    assert relerr(ref['comp_rgb_stack'], quiet['comp_rgb_stack']) > 1e-2          # the noise does change the render
+    m = _model(cfg, levels, int(fx['wseed']))
+    rgb, dist, acc = m(rays, t_rand=t_rand.cuda(), u_rand={l: u.cuda() for l, u in u_rand.items()},
+                       noise={l: z.cuda() for l, z in noise.items()})
+    assert relerr(rgb.cpu(), ref['comp_rgb_stack']) < 1e-4
+    assert relerr(acc.cpu(), ref['acc_stack']) < 1e-4
+    assert relerr(dist.cpu(), ref['distance_stack']) < 1e-4
