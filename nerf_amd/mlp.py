@@ -120,10 +120,11 @@ def mlp_forward_fp32(p, enc, view_rows, sar=False):
         raw_density = linear(hn, *_wb(p, 'final_density.1'))
     else:
         raw_density = linear(h, *_wb(p, 'final_density.0'))
-    if 'rgb_net0.0.weight' not in p:            # use_viewdirs=False: colour straight from the trunk (model.py:78-92,123)
-        return raw_density, linear(h, *_wb(p, 'final_rgb.0'), act='sigmoid')
-    g = linear(h, *_wb(p, 'rgb_net0.0'))
-    g = linear(torch.cat((g, view_rows), -1), *_wb(p, 'rgb_net1.0'), act='relu')
+    if 'rgb_net0.0.weight' not in p:            # use_viewdirs=False: heads straight on the trunk (model.py:78-92,123,283-302)
+        g = h
+    else:
+        g = linear(h, *_wb(p, 'rgb_net0.0'))
+        g = linear(torch.cat((g, view_rows), -1), *_wb(p, 'rgb_net1.0'), act='relu')
     raw_rgb = linear(g, *_wb(p, 'final_rgb.0'), act='sigmoid')
     if sar:
         return raw_density, raw_rgb, linear(g, *_wb(p, 'final_angle.0'), act='sigmoid')

@@ -286,25 +286,31 @@ class SARNeRF(_RenderModule):
         self.num_ray_iters = int(self.total_num_rays // self.rays_per_chunk)
         self.cube_dim = int(np.sqrt(self.rays_per_chunk))
         self.loss_function = SARNeRFLoss(config.coarse_weight_decay)
-        if not self.use_viewdirs:
-            raise NotImplementedError('the render kernels implement the view-dependent branch (use_viewdirs=True)')
-
         self.positional_encoding = PositionalEncoding(config.min_deg, config.max_deg)
         self._build_trunk(config)
         self.final_density = nn.Sequential(nn.LayerNorm(config.hidden), nn.Linear(config.hidden, 1))
-        self.rgb_net0 = nn.Sequential(nn.Linear(config.hidden, config.hidden))
-        self.viewdirs_encoding = PositionalEncoding(config.viewdirs_min_deg, config.viewdirs_max_deg)
-        self.rgb_net1 = nn.Sequential(nn.Linear(config.hidden + self.rgb_input, config.num_samples), nn.ReLU(True))
-        self.final_rgb = nn.Sequential(nn.Linear(config.num_samples, 3), nn.Sigmoid())
-        self.final_angle = nn.Sequential(nn.Linear(config.num_samples, 2), nn.Sigmoid())
+        input_shape = config.hidden
+        if self.use_viewdirs:
+            input_shape = config.num_samples
+            self.rgb_net0 = nn.Sequential(nn.Linear(config.hidden, config.hidden))
+            self.viewdirs_encoding = PositionalEncoding(config.viewdirs_min_deg, config.viewdirs_max_deg)
+            self.rgb_net1 = nn.Sequential(nn.Linear(config.hidden + self.rgb_input, config.num_samples), nn.ReLU(True))
+        elif getattr(config, 'mlp_precision', 'fp32') == 'bf16':
+            raise NotImplementedError("the fused bf16 chain implements the view-dependent network; with "
+                                      "use_viewdirs=False use mlp_precision='fp32'")
+        self.final_rgb = nn.Sequential(nn.Linear(input_shape, 3), nn.Sigmoid())
+        self.final_angle = nn.Sequential(nn.Linear(input_shape, 2), nn.Sigmoid())
         _xavier_init(self)
         self._packed = None
 
     def _query(self, enc, view_feat, R, S):
         # Row i of the MLP input belongs to ray i // S, but upstream tiles the [1,R,V] view features
         # along the *sample* axis (model.py:351-354), so row i receives the features of ray i mod R.
-        idx = torch.arange(R * S, device=enc.device) % R
-        return mlp.mlp_forward_fp32(self._param_dict(), enc, view_feat[idx], sar=True)
+        view_rows = None
+        if view_feat is not None:
+            idx = torch.arange(R * S, device=enc.device) % R
+            view_rows = view_feat[idx]
+        return mlp.mlp_forward_fp32(self._param_dict(), enc, view_rows, sar=True)
 
     def forward(self, ray_o, pan, tilt, mfilt, _radii, _near, _far, nsam, mpp, az_el=None, t_rand=None,
                 u_rand=None, rank=0, world_size=1):
@@ -341,7 +347,9 @@ class SARNeRF(_RenderModule):
                 continue                        # every rank walks the same CPU generator sequence)
             ray_d, ray_p = ops.sar_raygen(az.to(dev), el.to(dev))
             bf16 = self._precision() == 'bf16'
-            if bf16:
+            if not self.use_viewdirs:
+                view_feat = None
+            elif bf16:
                 from . import mlp_bf16
                 view_feat = mlp_bf16.view_frag(ray_d, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg)
             else:

@@ -342,8 +342,11 @@ def sar_cfg(**kw):
     return SimpleNamespace(**c)
 
 
-def gen_sar_e2e():
-    for tag, kw in (('rand', dict()), ('det', dict(randomized=False, total_num_rays=128))):
+def gen_sar_e2e(only=None):
+    for tag, kw in (('rand', dict()), ('det', dict(randomized=False, total_num_rays=128)),
+                    ('det_noview', dict(randomized=False, total_num_rays=128, use_viewdirs=False))):
+        if only is not None and tag not in only:
+            continue
         cfg = sar_cfg(**kw)
         m = R_model.SARNeRF(cfg)
         p = O.init_params(cfg, sar=True, seed=31)
@@ -452,6 +455,7 @@ if __name__ == '__main__':
         gen_ndc()
         sys.exit(0)
     if _ARGS == ['noview']:
+        gen_sar_e2e(only=('det_noview',))
         gen_nerf_e2e(only=('small_noview',))
         sys.exit(0)
     gen_ndc()

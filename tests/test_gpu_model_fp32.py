@@ -119,7 +119,7 @@ def test_state_dict_keys_match_reference_layout():
     assert sar_keys == set(O.init_params(cfg, sar=True)) | {'positional_encoding.scales', 'viewdirs_encoding.scales'}
 
 
-@pytest.mark.parametrize('tag', ['rand', 'det'])
+@pytest.mark.parametrize('tag', ['rand', 'det', 'det_noview'])
 def test_sar_end_to_end(golden, tag):
     """SARNeRF.forward against (a) the reference fixture and (b) the oracle at a long wavelength where the
     fp32 phase is well conditioned, so pulses and all 28 parameter gradients compare elementwise."""

@@ -141,7 +141,7 @@ def test_nerf_end_to_end(golden, tag):
             assert relerr(v.grad.reshape(-1)[::97][:256], T(fx['gslice_' + k])) < 5e-4, k
 
 
-@pytest.mark.parametrize('tag', ['rand', 'det'])
+@pytest.mark.parametrize('tag', ['rand', 'det', 'det_noview'])
 def test_sar_end_to_end(golden, tag):
     fx = golden('sar_e2e_' + tag)
     cfg = cfg_from(fx)
