@@ -19,7 +19,7 @@ import torch.nn as nn
 from torch import optim
 
 from . import mlp, ops
-from .util_modules import MipLRDecay, NeRFLoss, PositionalEncoding, SARNeRFLoss
+from .util_modules import MipLRDecay, NeRFLoss, PositionalEncoding, SARNeRFLoss, mse_to_psnr  # noqa: F401 (model.py:430 exports it too)
 from .utils import namedtuple_map
 
 SAR_AZ_SIGMA = 0.039269908169872414     # model.py:319
