@@ -278,6 +278,24 @@ def mlp_weight_grads(pk, acts, dys, n_samples, grads):
 
 PARAM_NAMES = [n + s for n in STREAMED + ['final_density.0', 'final_rgb.0'] for s in ('.weight', '.bias')]
 
+_ACCUMULATE_INTO_GRAD = False
+
+
+class accumulate_into_grad:
+    """Within this context the NeRF backward adds the weight gradients straight into each parameter's existing
+    `.grad` (the weight-gradient kernels accumulate with float atomics anyway) and hands autograd nothing for
+    them: no zero-filled temporaries, no `grad += temporary` per parameter and level.  Only for loops that own
+    their `.grad` buffers and read gradients from there (`train.nerf_train_step`); `torch.autograd.grad` and
+    hooks on the parameters would see no gradient, so it is opt-in."""
+
+    def __enter__(self):
+        global _ACCUMULATE_INTO_GRAD
+        self.prev, _ACCUMULATE_INTO_GRAD = _ACCUMULATE_INTO_GRAD, True
+
+    def __exit__(self, *exc):
+        global _ACCUMULATE_INTO_GRAD
+        _ACCUMULATE_INTO_GRAD = self.prev
+
 
 class _MlpNerf(torch.autograd.Function):
     """raw_density [M,1], raw_rgb [M,3] = MLP(enc frags, view frags); gradients flow to the 24 parameters."""
@@ -289,6 +307,7 @@ class _MlpNerf(torch.autograd.Function):
         d, rgb, _, acts, _ = mlp_forward(pk, encf, viewf, n_samples, ray_div, n_rays, save=need_grad)
         ctx.pk, ctx.acts, ctx.n = pk, acts, n_samples
         ctx.shapes = [(p.shape, p.device) for p in params]
+        ctx.params = params
         ctx.save_for_backward(rgb)
         return d.reshape(-1, 1), rgb
 
@@ -297,9 +316,16 @@ class _MlpNerf(torch.autograd.Function):
         (rgb,) = ctx.saved_tensors
         pk = ctx.pk
         dys = mlp_backward(pk, ctx.acts, ctx.n, g_density, g_rgb, rgb)
-        grads = {n: torch.zeros(shape, device=dev, dtype=torch.float32) for n, (shape, dev) in zip(PARAM_NAMES, ctx.shapes)}
+        in_place = _ACCUMULATE_INTO_GRAD and all(
+            q.grad is not None and q.grad.dtype == torch.float32 and q.grad.is_contiguous() for q in ctx.params)
+        if in_place:
+            grads = {n: q.grad for n, q in zip(PARAM_NAMES, ctx.params)}
+        else:
+            grads = {n: torch.zeros(shape, device=dev, dtype=torch.float32) for n, (shape, dev) in zip(PARAM_NAMES, ctx.shapes)}
         mlp_weight_grads(pk, ctx.acts, dys, ctx.n, grads)
-        ctx.acts = None
+        ctx.acts = ctx.params = None
+        if in_place:
+            return (None,) * (6 + len(PARAM_NAMES))
         return (None, None, None, None, None, None) + tuple(grads[n] for n in PARAM_NAMES)
 
 

@@ -79,13 +79,19 @@ def nerf_train_step(model, rays, pixels, optimizer, chunk=8192, world_size=1, gl
             p.grad = torch.zeros_like(p)
     total = torch.zeros((), device=rays.origins.device)
     cwd = model.loss_function.coarse_weight_decay
-    for i in range(0, n, chunk):
-        r = namedtuple_map(lambda t: t[i:i + chunk], rays)
-        rgb = model(r)[0]
-        sq = (r.lossmult * (rgb - pixels[i:i + chunk][None]) ** 2).sum(dim=(1, 2)) / global_mask_sum
-        loss = cwd * sq[:-1].sum() + sq[-1]
-        loss.backward()
-        total += loss.detach()
+    import contextlib
+    in_place = contextlib.nullcontext()
+    if getattr(model.config, 'mlp_precision', 'fp32') == 'bf16':
+        from .mlp_bf16 import accumulate_into_grad
+        in_place = accumulate_into_grad()           # the .grad buffers exist (above) and are read from below
+    with in_place:
+        for i in range(0, n, chunk):
+            r = namedtuple_map(lambda t: t[i:i + chunk], rays)
+            rgb = model(r)[0]
+            sq = (r.lossmult * (rgb - pixels[i:i + chunk][None]) ** 2).sum(dim=(1, 2)) / global_mask_sum
+            loss = cwd * sq[:-1].sum() + sq[-1]
+            loss.backward()
+            total += loss.detach()
     allreduce_grads(params, world_size)
     optimizer.step()
     if scheduler is not None:

@@ -255,3 +255,37 @@ def test_packed_weights_follow_parameter_updates():
                 q.add_(0.05)
         c = mlp_bf16.query_nerf(m, t, r, viewf, 16)[0]
         assert not torch.equal(b, c)
+
+
+def test_in_place_gradient_accumulation_matches_autograd():
+    """`accumulate_into_grad`: the weight gradients added straight into existing `.grad` buffers (on top of what
+    they hold) equal what autograd accumulates from returned tensors; outside the context nothing changes."""
+    from nerf_amd import mlp_bf16
+    from nerf_amd.model import MipNeRF
+    from nerf_amd.utils import Rays
+    cfg = make_cfg(hidden=64, num_samples=16, max_deg=4)
+    cfg.mlp_precision = 'bf16'
+    torch.manual_seed(0)
+    m = MipNeRF(cfg).cuda().train()
+    m.randomized = False
+    r = make_rays(41, 2)
+    r = Rays(*(getattr(r, f).cuda() for f in Rays._fields))
+    tgt = torch.rand(41, 3, device='cuda')
+    params = [p for p in m.parameters() if p.requires_grad]
+
+    def run(in_place):
+        for p in params:
+            p.grad = torch.full_like(p, 0.25)            # running gradients the step must add to
+        loss = ((m(r)[0] - tgt[None]) ** 2).mean()
+        if in_place:
+            with mlp_bf16.accumulate_into_grad():
+                loss.backward()
+        else:
+            loss.backward()
+        return [p.grad.clone() for p in params]
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert float((x - 0.25).abs().max()) > 0                       # a gradient did arrive
+        # atomics add onto 0.25 term by term, autograd adds one finished sum: a few ulps of 0.25 apart
+        assert float((x - y).abs().max()) <= 1e-5 * float((x - 0.25).abs().max()) + 3e-7
