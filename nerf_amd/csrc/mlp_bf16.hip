@@ -999,6 +999,10 @@ __global__ void pack_bwd2_kernel(const float* __restrict__ W, int ld, int n_true
 // (a2)+(a3) fused: fenceposts -> conical frustum / cylinder Gaussian -> integrated positional
 // encoding, written straight in frag order (bf16).  One thread per (sample, lane half).
 //                                         reference: utils.py:130-137,162-164,91-100; util_modules.py:37-44
+// LT > 0: the number of octaves is a compile-time constant, so each fragment element's (octave, axis, phase) is
+// known per lane half and the loop below reduces to selects between two constants; LT = 0 takes L at run time.
+// Both evaluate the same expression per feature.
+template <int LT>
 __global__ void encode_frag_kernel(const float* __restrict__ t_vals, const float* __restrict__ origins,
                                    const float* __restrict__ directions, const float* __restrict__ radii,
                                    int64_t n_rays, int S, int ray_shape, int min_deg, int L, int DKS, int64_t nblk,
@@ -1043,6 +1047,36 @@ __global__ void encode_frag_kernel(const float* __restrict__ t_vals, const float
             mean[k] = d[k] * t_mean + origins[ray * 3 + k];
             cov[k] = t_var * d2[k] + r_var * (1.f - d2[k] / dmag);
         }
+    }
+    if constexpr (LT > 0) {
+        constexpr int F = 3 * LT, KS = (6 * LT + 15) / 16;
+        const float scale0 = ldexpf(1.f, min_deg);
+        const bool hi = h != 0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // the two features this element can be: lane half 0 and lane half 1
+                const int fa = ks * 16 + frag_feat(j, 0), fb = ks * 16 + frag_feat(j, 1);
+                const int ka = fa < F ? fa : fa - F, kb = fb < F ? fb : fb - F;
+                const bool va = fa < 2 * F, vb = fb < 2 * F;
+                const int la = va ? ka / 3 : 0, lb = vb ? kb / 3 : 0;
+                const int ca = va ? ka - 3 * la : 0, cb = vb ? kb - 3 * lb : 0;
+                const float s1 = scale0 * (hi ? (float)(1 << lb) : (float)(1 << la));
+                const float mu = hi ? mean[cb] : mean[ca];
+                const float cv = hi ? cov[cb] : cov[ca];
+                const float ph = hi ? (fb < F ? 0.f : 1.5707963267948966f) : (fa < F ? 0.f : 1.5707963267948966f);
+                const bool valid = ok && (hi ? vb : va);
+                const float x = mu * s1 + ph;
+                const float turns = x * 0.15915494309189535f;
+                const float v = __builtin_amdgcn_exp2f(-0.72134752044448170f * (cv * (s1 * s1))) *
+                                __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(turns));
+                o[j] = (__bf16)(valid ? v : 0.f);
+            }
+            enc[((blk * KS + ks) * 2 + ct) * 64 + lane] = o;
+        }
+        return;
     }
     const int F = 3 * L;
     for (int ks = 0; ks < DKS; ++ks) {
@@ -1221,9 +1255,15 @@ extern "C" int nerf_encode_frag(const float* t_vals, const float* origins, const
     const int L = max_deg - min_deg;
     const int DKS = (6 * L + 15) / 16;
     const int64_t nblk = ((n_rays * num_samples + 255) / 256) * 4;   // whole workgroups of the MLP kernels; padding is zero
-    hipLaunchKernelGGL(encode_frag_kernel, dim3(nerf_blocks(nblk * 128, 256)), dim3(256), 0, nerf_stream(stream),
-                       t_vals, origins, directions, radii, n_rays, num_samples, ray_shape, min_deg, L, DKS, nblk,
-                       (bf16x8*)enc_frag);
+#define NERF_ENCODE(LT)                                                                                              \
+    hipLaunchKernelGGL(encode_frag_kernel<LT>, dim3(nerf_blocks(nblk * 128, 256)), dim3(256), 0, nerf_stream(stream), \
+                       t_vals, origins, directions, radii, n_rays, num_samples, ray_shape, min_deg, L, DKS, nblk,      \
+                       (bf16x8*)enc_frag)
+    if (L == 10) NERF_ENCODE(10);
+    else if (L == 16) NERF_ENCODE(16);
+    else if (L == 4) NERF_ENCODE(4);
+    else NERF_ENCODE(0);
+#undef NERF_ENCODE
     return nerf_launch_status();
 }
 
