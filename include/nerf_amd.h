@@ -272,9 +272,10 @@ typedef struct nerf_wgrad_desc {
 } nerf_wgrad_desc;
 int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint, void* stream);
 
-/* The mlp_wgrad_kernel<nw, tn, tk> instantiation a weight-gradient launch with these total padded feature
- * counts uses, so a profiler can label launches by kernel symbol.  (No reference counterpart: measurement support.) */
-int nerf_mlp_wgrad_config(int n_feat, int k_feat, int* nw, int* tn, int* tk);
+/* The mlp_wgrad_kernel<nw, tn, tk, gt> instantiation a weight-gradient launch with these total padded feature
+ * counts uses (gt = compile-time loads per wave and k-step, 0 = run-time count), so a profiler can label launches
+ * by kernel symbol.  (No reference counterpart: measurement support.) */
+int nerf_mlp_wgrad_config(int n_feat, int k_feat, int* nw, int* tn, int* tk, int* gt);
 
 #ifdef __cplusplus
 }

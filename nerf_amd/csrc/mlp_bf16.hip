@@ -748,7 +748,9 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 #undef NERF_W1
 }
 
-template <int NW, int NTW, int KTW>        // NW waves (4 or 8), each owning NTW x KTW output tiles
+// GT > 0: the loads per wave and k-step are the compile-time GT (the host checks) and go out between the rows of
+// MFMAs; GT = 0: any count, all issued at the top of the k-step.
+template <int NW, int NTW, int KTW, int GT = 0>        // NW waves (4 or 8), each owning NTW x KTW output tiles
 __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave / a.WK, wk = wave % a.WK;
     const int P = a.NT + a.KT;                         // pieces per k-step
-    const int G = (P + NW - 1) / NW;                   // loads per wave per k-step (1..5), same for every wave
+    const int G = GT > 0 ? GT : (P + NW - 1) / NW;     // loads per wave per k-step (1..5), same for every wave
     const unsigned slot_bytes = P * 1024;
     LDS_AS char* ring = (LDS_AS char*)smem;
     const int depth = a.depth;
@@ -800,20 +802,32 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
         ld_dst[g] = p * 1024;
     }
     int fill = 0, drain = 0;                           // ring positions of the next k-step to load / to consume
-    auto issue = [&](int64_t i) {
-        const int64_t q = 2 * (q0 + (i >> 1) * qstride) + (i & 1);
-        LDS_AS char* slot = ring + (unsigned)fill * slot_bytes;
+    // The loads of one k-step: begin_issue(i) fixes where they come from and go to, issue_load(g) issues load g.
+    // In the steady state they are issued one at a time between the rows of MFMAs (multiply()): a load that finds
+    // the CU's request queue full holds the wave at that instruction, and issued back to back at the top of the
+    // k-step the G loads did so for 40 % of it with the matrix pipe idle; spread out, the MFMAs already issued run
+    // under the wait and the queue never drains.
+    int64_t is_q = 0;
+    LDS_AS char* is_slot = ring;
+    bool is_live = false;
+    auto begin_issue = [&](int64_t i) {
+        is_q = 2 * (q0 + (i >> 1) * qstride) + (i & 1);
+        is_slot = ring + (unsigned)fill * slot_bytes;
         fill = fill + 1 == depth ? 0 : fill + 1;
-        const bool live = i < n;
-#pragma unroll
-        for (int g = 0; g < 5; ++g) {
-            if (g < G) {
-                const bool real = live && ld_real[g];
-                const char* src = real ? ld_base[g] + q * ld_stride[g] : (const char*)a.A[0].p;
-                LDS_AS char* dst = real ? slot + ld_dst[g] : scratch + wave * 1024;
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + lane * 16), (LDS_AS void*)dst, 16, 0, 0);
-            }
+        is_live = i < n;
+    };
+    auto issue_load = [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if (g < G) {
+            const bool real = is_live && ld_real[g];
+            const char* src = real ? ld_base[g] + is_q * ld_stride[g] : (const char*)a.A[0].p;
+            LDS_AS char* dst = real ? is_slot + ld_dst[g] : scratch + wave * 1024;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + lane * 16), (LDS_AS void*)dst, 16, 0, 0);
         }
+    };
+    auto issue = [&](int64_t i) {
+        begin_issue(i);
+        static_for<0, 5>([&](auto gc) __attribute__((always_inline)) { issue_load(gc); });
     };
 
     auto read_operands = [&](LDS_AS const char* slot, bf16x8 (&A)[NTW], bf16x8 (&B)[KTW]) {
@@ -830,9 +844,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
     };
     // MFMAs of one k-step; the column sums of dY (bias gradient) ride along on the vector ALU, branch-free so that
     // they are scheduled between the MFMAs (waves that do not own the bias just do not flush them)
-    auto multiply = [&](const bf16x8 (&A)[NTW], const bf16x8 (&B)[KTW]) {
-#pragma unroll
-        for (int ii = 0; ii < NTW; ++ii) {
+    // (the loads of k-step `i_load` go out between the rows: load g ahead of row g * NTW / G)
+    auto multiply = [&](const bf16x8 (&A)[NTW], const bf16x8 (&B)[KTW], int64_t i_load) {
+        if constexpr (GT > 0) begin_issue(i_load);
+        else issue(i_load);
+        static_for<0, NTW>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int ii = decltype(ic)::value;
+            static_for<0, 5>([&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value;
+                if constexpr (GT > 0 && g < GT && (g * NTW) / (GT > 0 ? GT : 1) == ii) issue_load(gc);
+            });
 #pragma unroll
             for (int j = 0; j < KTW; ++j) acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ii], B[j], acc[ii][j], 0, 0, 0);
             const u32x4 d = __builtin_bit_cast(u32x4, A[ii]);
@@ -840,7 +861,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
 #pragma unroll
             for (int q = 0; q < 4; ++q) t += __uint_as_float(d[q] << 16) + __uint_as_float(d[q] & 0xffff0000u);
             accb[ii] += t;
-        }
+            if constexpr (GT > 0) __builtin_amdgcn_sched_barrier(0);
+        });
     };
     auto slot_of = [&](int pos) { return ring + (unsigned)pos * slot_bytes; };
     auto next_pos = [&](int pos) { return pos + 1 == depth ? 0 : pos + 1; };
@@ -860,27 +882,24 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
         for (int64_t i = 0; i < n; i += 2) {            // n is even
             wait_vmcnt(in_flight);                      // this wave's pieces of k-step i+1 have landed
             __builtin_amdgcn_s_barrier();               // everyone's have; everyone is done reading k-step i's slot
-            issue(i + depth - 1);
             drain = next_pos(drain);
             read_operands(slot_of(drain), A1, B1);      // k-step i+1
-            multiply(A0, B0);
+            multiply(A0, B0, i + depth - 1);
             wait_vmcnt(in_flight);
             __builtin_amdgcn_s_barrier();
-            issue(i + depth);
             drain = next_pos(drain);
             read_operands(slot_of(drain), A0, B0);      // k-step i+2 (unused garbage past the end)
-            multiply(A1, B1);
+            multiply(A1, B1, i + depth);
         }
     } else {
         const int in_flight = (depth - 2) * G;
         for (int64_t i = 0; i < n; ++i) {
             wait_vmcnt(in_flight);
             __builtin_amdgcn_s_barrier();
-            issue(i + depth - 1);
             bf16x8 A[NTW], B[KTW];
             read_operands(slot_of(drain), A, B);
             drain = next_pos(drain);
-            multiply(A, B);
+            multiply(A, B, i + depth - 1);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS write may outlive the workgroup
@@ -1380,19 +1399,29 @@ static bool wgrad_config(int NT, int KT, int* NW, int* WN, int* WK, int* tn, int
     return *tn != 0;
 }
 
-// Which mlp_wgrad_kernel<nw, tn, tk> instantiation a launch with these total padded feature counts uses
-// (profilers label launches with it).
-extern "C" int nerf_mlp_wgrad_config(int n_feat, int k_feat, int* nw, int* tn, int* tk) {
-    int wn, wk;
-    NERF_REQUIRE(nw && tn && tk && n_feat > 0 && k_feat > 0 && n_feat % 32 == 0 && k_feat % 32 == 0);
-    return wgrad_config(n_feat / 32, k_feat / 32, nw, &wn, &wk, tn, tk) ? NERF_OK : NERF_ERR_SIZE;
+// Instantiations with a compile-time load count exist for the shapes of the 8 x 256 network: -> that count, else 0.
+static int wgrad_static_loads(int nw, int tn, int tk, int loads) {
+    static const int kStatic[6][4] = {{4, 4, 4, 4}, {8, 4, 3, 3}, {8, 5, 2, 3}, {4, 2, 5, 4}, {4, 2, 2, 3}, {4, 1, 1, 2}};
+    for (const auto& v : kStatic)
+        if (v[0] == nw && v[1] == tn && v[2] == tk && v[3] == loads) return loads;
+    return 0;
 }
 
-template <int NW, int NTW, int KTW>
+// Which mlp_wgrad_kernel<nw, tn, tk, gt> instantiation a launch with these total padded feature counts uses
+// (profilers label launches with it).
+extern "C" int nerf_mlp_wgrad_config(int n_feat, int k_feat, int* nw, int* tn, int* tk, int* gt) {
+    int wn, wk;
+    NERF_REQUIRE(nw && tn && tk && gt && n_feat > 0 && k_feat > 0 && n_feat % 32 == 0 && k_feat % 32 == 0);
+    if (!wgrad_config(n_feat / 32, k_feat / 32, nw, &wn, &wk, tn, tk)) return NERF_ERR_SIZE;
+    *gt = wgrad_static_loads(*nw, *tn, *tk, (n_feat / 32 + k_feat / 32 + *nw - 1) / *nw);
+    return NERF_OK;
+}
+
+template <int NW, int NTW, int KTW, int GT = 0>
 static int launch_wgrad(const WgradArgs& a, unsigned grid, size_t lds, hipStream_t st) {
     static std::atomic<unsigned long long> done{0};
-    if (!allow_dynamic_lds((const void*)mlp_wgrad_kernel<NW, NTW, KTW>, kWgradLds, done)) return NERF_ERR_LAUNCH;
-    hipLaunchKernelGGL((mlp_wgrad_kernel<NW, NTW, KTW>), dim3(grid), dim3(64 * NW), lds, st, a);
+    if (!allow_dynamic_lds((const void*)mlp_wgrad_kernel<NW, NTW, KTW, GT>, kWgradLds, done)) return NERF_ERR_LAUNCH;
+    hipLaunchKernelGGL((mlp_wgrad_kernel<NW, NTW, KTW, GT>), dim3(grid), dim3(64 * NW), lds, st, a);
     return nerf_launch_status();
 }
 
@@ -1427,6 +1456,15 @@ extern "C" int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples,
     if (a.depth < 3) return NERF_ERR_SIZE;
     const size_t lds = (size_t)(a.depth * pieces + nw) * 1024;
     hipStream_t st = nerf_stream(stream);
+    // the shapes of the 8 x 256 network get the variants with a compile-time load count (loads between the MFMA rows)
+    if (const int gt = wgrad_static_loads(nw, tn, tk, loads)) {
+        if (nw == 8) return tn == 4 ? launch_wgrad<8, 4, 3, 3>(a, grid, lds, st) : launch_wgrad<8, 5, 2, 3>(a, grid, lds, st);
+        if (tn == 4) return launch_wgrad<4, 4, 4, 4>(a, grid, lds, st);
+        if (tk == 5) return launch_wgrad<4, 2, 5, 4>(a, grid, lds, st);
+        if (tn == 2) return launch_wgrad<4, 2, 2, 3>(a, grid, lds, st);
+        (void)gt;
+        return launch_wgrad<4, 1, 1, 2>(a, grid, lds, st);
+    }
     if (nw == 8) return tn == 4 ? launch_wgrad<8, 4, 3>(a, grid, lds, st) : launch_wgrad<8, 5, 2>(a, grid, lds, st);
     if (tn == 1 && tk == 1) return launch_wgrad<4, 1, 1>(a, grid, lds, st);
     if (tn == 1 && tk == 2) return launch_wgrad<4, 1, 2>(a, grid, lds, st);

@@ -239,9 +239,10 @@ def wgrad_kernel_name(n_feat, k_feat):
     """Symbol of the kernel instantiation that handles these feature counts."""
     key = (n_feat, k_feat)
     if key not in _WGRAD_KERNEL:
-        nw, tn, tk = c_int(), c_int(), c_int()
-        check(lib().nerf_mlp_wgrad_config(n_feat, k_feat, ctypes.byref(nw), ctypes.byref(tn), ctypes.byref(tk)))
-        _WGRAD_KERNEL[key] = 'mlp_wgrad_kernel<%d, %d, %d>' % (nw.value, tn.value, tk.value)
+        nw, tn, tk, gt = c_int(), c_int(), c_int(), c_int()
+        check(lib().nerf_mlp_wgrad_config(n_feat, k_feat, ctypes.byref(nw), ctypes.byref(tn), ctypes.byref(tk),
+                                          ctypes.byref(gt)))
+        _WGRAD_KERNEL[key] = 'mlp_wgrad_kernel<%d, %d, %d, %d>' % (nw.value, tn.value, tk.value, gt.value)
     return _WGRAD_KERNEL[key]
 
 

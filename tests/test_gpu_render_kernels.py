@@ -389,11 +389,12 @@ def test_c_abi_rejects_bad_arguments():
     # zero-sized calls are valid no-ops whatever the pointers
     assert L.nerf_pe_encode(null, 0, 0, 4, 0, null, None) == 0
     assert L.nerf_convert_to_ndc(null, null, 0, 10.0, 8, 8, 1.0, null, null, None) == 0
-    nw, tn, tk = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    assert L.nerf_mlp_wgrad_config(256, 256, ctypes.byref(nw), ctypes.byref(tn), ctypes.byref(tk)) == 0
-    assert (nw.value, tn.value, tk.value) == (4, 4, 4)
-    assert L.nerf_mlp_wgrad_config(31, 256, ctypes.byref(nw), ctypes.byref(tn), ctypes.byref(tk)) < 0   # not a multiple of 32
-    assert L.nerf_mlp_wgrad_config(4096, 4096, ctypes.byref(nw), ctypes.byref(tn), ctypes.byref(tk)) == ERR_SIZE
+    nw, tn, tk, gt = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    out = [ctypes.byref(v) for v in (nw, tn, tk, gt)]
+    assert L.nerf_mlp_wgrad_config(256, 256, *out) == 0
+    assert (nw.value, tn.value, tk.value, gt.value) == (4, 4, 4, 4)
+    assert L.nerf_mlp_wgrad_config(31, 256, *out) < 0                             # not a multiple of 32
+    assert L.nerf_mlp_wgrad_config(4096, 4096, *out) == ERR_SIZE
     assert float(buf.abs().sum()) == 0.0                                        # nothing was written
     for code in (-1, -2, -3, -4):
         assert len(L.nerf_error_string(code)) > 0
