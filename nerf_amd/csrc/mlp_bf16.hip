@@ -750,6 +750,9 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 
 // GT > 0: the loads per wave and k-step are the compile-time GT (the host checks) and go out between the rows of
 // MFMAs; GT = 0: any count, all issued at the top of the k-step.
+#ifndef NERF_WG_D
+#define NERF_WG_D 6      // 4: 5.0, 6: 5.2, 8: 3.2 TB/s over the launches of one backward pass (8 runs out of registers)
+#endif
 template <int NW, int NTW, int KTW, int GT = 0>        // NW waves (4 or 8), each owning NTW x KTW output tiles
 __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -845,14 +848,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
     // MFMAs of one k-step; the column sums of dY (bias gradient) ride along on the vector ALU, branch-free so that
     // they are scheduled between the MFMAs (waves that do not own the bias just do not flush them)
     // (the loads of k-step `i_load` go out between the rows: load g ahead of row g * NTW / G)
-    auto multiply = [&](const bf16x8 (&A)[NTW], const bf16x8 (&B)[KTW], int64_t i_load) {
-        if constexpr (GT > 0) begin_issue(i_load);
-        else issue(i_load);
+    auto multiply_with = [&](const bf16x8 (&A)[NTW], const bf16x8 (&B)[KTW], auto&& load_g) {
         static_for<0, NTW>([&](auto ic) __attribute__((always_inline)) {
             constexpr int ii = decltype(ic)::value;
             static_for<0, 5>([&](auto gc) __attribute__((always_inline)) {
                 constexpr int g = decltype(gc)::value;
-                if constexpr (GT > 0 && g < GT && (g * NTW) / (GT > 0 ? GT : 1) == ii) issue_load(gc);
+                if constexpr (GT > 0 && g < GT && (g * NTW) / (GT > 0 ? GT : 1) == ii) load_g(gc);
             });
 #pragma unroll
             for (int j = 0; j < KTW; ++j) acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ii], B[j], acc[ii][j], 0, 0, 0);
@@ -864,11 +865,73 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
             if constexpr (GT > 0) __builtin_amdgcn_sched_barrier(0);
         });
     };
+    auto multiply = [&](const bf16x8 (&A)[NTW], const bf16x8 (&B)[KTW], int64_t i_load) {
+        if constexpr (GT > 0) begin_issue(i_load);
+        else issue(i_load);
+        multiply_with(A, B, issue_load);
+    };
     auto slot_of = [&](int pos) { return ring + (unsigned)pos * slot_bytes; };
     auto next_pos = [&](int pos) { return pos + 1 == depth ? 0 : pos + 1; };
 
-    for (int i = 0; i < depth - 1; ++i) issue(i);
-    if constexpr (NW == 4) {
+    if constexpr (NW == 4 && GT > 0) {
+        // Register path: a wave's GT pieces of a k-step are loaded into registers (RD k-steps in a compile-time
+        // ring of register sets, RD - 1 in flight), written to one of three LDS slots once they have arrived, and
+        // read back as operands after the barrier, one k-step ahead of the MFMAs as below.  Plain loads to
+        // registers stream faster than LDS-direct loads (7.3 against 6.3 TB/s in this very step structure,
+        // tools/microbench/read_paths.hip), and three slots replace the deep ring.
+        constexpr int RD = NERF_WG_D;                      // register sets: RD - 1 k-steps in flight (even)
+        bf16x8 R[RD][GT];
+        bf16x8 A0[NTW], B0[KTW], A1[NTW], B1[KTW];
+        bf16x8 zero;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zero[j] = (__bf16)0.f;
+        auto load_step = [&](auto dc, int64_t i, auto gc) {          // load g of k-step i into register set d
+            constexpr int d = decltype(dc)::value, g = decltype(gc)::value;
+            const int64_t q = 2 * (q0 + (i >> 1) * qstride) + (i & 1);
+            const bool real = i < n && ld_real[g];
+            const char* src = real ? ld_base[g] + q * ld_stride[g] : (const char*)a.A[0].p;
+            R[d][g] = __builtin_nontemporal_load((const bf16x8*)src + lane);
+        };
+        auto publish = [&](auto dc, int64_t i) {                      // register set d = k-step i -> its LDS slot
+            constexpr int d = decltype(dc)::value;
+            LDS_AS char* slot = ring + (unsigned)(i % 3) * slot_bytes;
+            const bool live = i < n;
+            static_for<0, GT>([&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value;
+                if (ld_real[g]) *(LDS_AS bf16x8*)(slot + ld_dst[g] + lane * 16) = live ? R[d][g] : zero;
+            });
+        };
+        if (n > 0) {
+            static_for<0, RD>([&](auto dc) __attribute__((always_inline)) {
+                static_for<0, GT>([&](auto gc) __attribute__((always_inline)) { load_step(dc, decltype(dc)::value, gc); });
+            });
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RD - 1) * GT) : "memory");
+            publish(IC<0>{}, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the barrier does not wait for LDS writes
+            __builtin_amdgcn_s_barrier();
+            read_operands(ring, A0, B0);
+        }
+        for (int64_t i = 0; i < n; i += RD) {               // k-steps past n (n is even) are published as zeros
+            static_for<0, RD>([&](auto dc) __attribute__((always_inline)) {
+                constexpr int d = decltype(dc)::value;
+                const int64_t t = i + d;
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RD - 2) * GT) : "memory");   // k-step t+1 has arrived
+                publish(IC<(d + 1) % RD>{}, t + 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                LDS_AS char* next = ring + (unsigned)((t + 1) % 3) * slot_bytes;
+                auto reload = [&](auto gc) __attribute__((always_inline)) { load_step(dc, t + RD, gc); };
+                if constexpr (d % 2 == 0) {
+                    read_operands(next, A1, B1);
+                    multiply_with(A0, B0, reload);
+                } else {
+                    read_operands(next, A0, B0);
+                    multiply_with(A1, B1, reload);
+                }
+            });
+        }
+    } else if constexpr (NW == 4) {
+        for (int i = 0; i < depth - 1; ++i) issue(i);
         // One wave per SIMD: nothing but this wave's own instruction stream hides LDS latency, so the operand reads
         // run one k-step ahead of the MFMAs.  At the top of iteration i, k-step i is in registers and k-step i+1 has
         // landed; two iterations per trip so the two register sets need no copies.
@@ -892,6 +955,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
             multiply(A1, B1, i + depth);
         }
     } else {
+        for (int i = 0; i < depth - 1; ++i) issue(i);
         const int in_flight = (depth - 2) * G;
         for (int64_t i = 0; i < n; ++i) {
             wait_vmcnt(in_flight);

@@ -50,6 +50,40 @@ __global__ void read_reg(const u32x4* __restrict__ src, long pieces, unsigned* s
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = acc.x;
 }
 
+// The weight-gradient kernel's shape on the register path: per k-step every wave loads G pieces into registers,
+// D k-steps in flight (a compile-time ring of register sets), writes an arrived k-step into an LDS slot
+// (two slots), barrier, every wave reads 2*G pieces back.
+template <int G, int D>
+__global__ __launch_bounds__(256) void read_reg_steps(const u32x4* __restrict__ src, long steps, unsigned* sink) {
+    __shared__ u32x4 slot[2][4 * G * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long stride = gridDim.x;
+    u32x4 v[D][G];
+    u32x4 acc = {0, 0, 0, 0};
+    long q = blockIdx.x;
+    auto load = [&](u32x4 (&r)[G], long qq) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) r[g] = __builtin_nontemporal_load(&src[((qq * 4 * G) + g * 4 + wave) * 64 + lane]);
+    };
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) load(v[d], q + d * stride);
+    int par = 0;
+    for (; q + (2 * D - 1) * stride < steps; q += D * stride) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            load(v[(d + D - 1) % D], q + (d + D - 1) * stride);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * G) : "memory");
+#pragma unroll
+            for (int g = 0; g < G; ++g) slot[par][(g * 4 + wave) * 64 + lane] = v[d][g];
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 2 * G; ++g) acc ^= slot[par][((g * 2 + (wave & 1)) % (4 * G)) * 64 + lane];
+            par ^= 1;
+        }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = acc.x;
+}
+
 template <class F>
 void timeit(const char* name, long bytes, F launch) {
     hipEvent_t e0, e1;
@@ -82,6 +116,10 @@ int main() {
     timeit("reg path, 256 WG x 8 waves, 16 in flight", bytes, [&] { hipLaunchKernelGGL(read_reg<16>, dim3(256), dim3(512), 0, 0, (const u32x4*)src, pieces, sink); });
     timeit("reg path, 256 WG x 16 waves, 8 in flight", bytes, [&] { hipLaunchKernelGGL(read_reg<8>, dim3(256), dim3(1024), 0, 0, (const u32x4*)src, pieces, sink); });
     timeit("reg path, 2048 WG x 4 waves, 8 in flight", bytes, [&] { hipLaunchKernelGGL(read_reg<8>, dim3(2048), dim3(256), 0, 0, (const u32x4*)src, pieces, sink); });
+    const long steps = bytes / (16 * 1024);
+    timeit("reg steps, G=4, 4 k-steps in flight", bytes, [&] { hipLaunchKernelGGL((read_reg_steps<4, 4>), dim3(256), dim3(256), 0, 0, (const u32x4*)src, steps, sink); });
+    timeit("reg steps, G=4, 6 k-steps in flight", bytes, [&] { hipLaunchKernelGGL((read_reg_steps<4, 6>), dim3(256), dim3(256), 0, 0, (const u32x4*)src, steps, sink); });
+    timeit("reg steps, G=4, 8 k-steps in flight", bytes, [&] { hipLaunchKernelGGL((read_reg_steps<4, 8>), dim3(256), dim3(256), 0, 0, (const u32x4*)src, steps, sink); });
     hipFree(src);
     hipFree(sink);
     return 0;
