@@ -191,7 +191,8 @@ constexpr int kLdsAhead = NERF_LDS_AHEAD;     // weight pieces in flight LDS -> 
 // fetch its weights kRing-1 stages ahead, then per tile run the MFMAs and -- under them -- finish the PREVIOUS
 // tile (bias, activation, conversion, transposition, stores).  The last tile of a layer is finished after the
 // layer's last stage, i.e. ahead of the next stage's fetch.  Program order of a wave's vector-memory operations
-// within stage k:   pre stores | fetch of stage k+kRing-1 (stage_loads) | extra loads | stores.
+// within stage k:   pre stores | extra loads | fetch of stage k+kRing-1 (stage_loads, spread under the first
+// tile's MFMAs) | stores.
 struct StageDesc { int ks, pre, xloads, stores; };      // ks = pieces of the whole stage
 
 // Forward layers: L0, L1-3, L4, L5-7 (HT tiles each), density head (1), L8 (HT), L9 (WT), colour heads (1).
@@ -252,7 +253,7 @@ constexpr int fwd_younger(int s) {
 }
 template <class N>
 constexpr int bwd_younger(int s) {
-    int y = bwd_stage<N>(s + 2 - kRing).xloads + bwd_stage<N>(s + 2 - kRing).stores;
+    int y = bwd_stage<N>(s + 2 - kRing).stores;      // (that stage's extra loads precede its fetch)
     for (int k = s + 3 - kRing; k <= s; ++k)
         y += bwd_stage<N>(k).pre + stage_loads(bwd_stage<N>(k + kRing - 1).ks) + bwd_stage<N>(k).xloads + bwd_stage<N>(k).stores;
     return y;
@@ -295,6 +296,25 @@ struct WeightPipe {
     }
     template <int KS>
     __device__ __forceinline__ void prefetch() { fetch<KS>((cur + kRing - 1) % kRing); }
+    // The same fetch one load at a time (between the MFMAs of the stage's first tile): begin_prefetch, then
+    // prefetch_piece<KS, p> for p = 0 .. stage_loads(KS) - 1.
+    const char* pf_src;
+    LDS_AS char* pf_dst;
+    template <int KS>
+    __device__ __forceinline__ void begin_prefetch() {
+        pf_src = src;
+        pf_dst = ring + ((cur + kRing - 1) % kRing) * slot_bytes;
+        src += KS * 1024;
+    }
+    template <int KS, int p>
+    __device__ __forceinline__ void prefetch_piece() {
+        if constexpr (p < stage_loads(KS)) {
+            const int piece = p * kWaves + wave;
+            const bool real = (p + 1) * kWaves <= KS || piece < KS;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)((real ? pf_src + piece * 1024 : base) + lane * 16),
+                                             (LDS_AS void*)(real ? pf_dst + piece * 1024 : ring + kRing * slot_bytes), 16, 0, 0);
+        }
+    }
     // Start of the kernel: stages 0 .. kRing-2 into slots 0 .. kRing-2, wait for all of them.
     template <int KS0, int KS1, int KS2, int KS3>
     __device__ __forceinline__ void prime() {
@@ -322,13 +342,13 @@ struct WeightPipe {
     // acc += W_tile * X over the KS k-steps of the current slot; B operand of k-step ks = b(IC<ks>).  The LDS
     // reads run kLdsAhead pieces ahead of the MFMAs behind counted lgkmcnt waits (LDS returns in order), so
     // that a wave's MFMAs are not each held up by a full LDS round trip.
-    template <int KS, int P0, class B>     // the tile's pieces are P0 .. P0+KS-1 of the slot
-    __device__ __forceinline__ void tile(f32x16& acc, B&& b) const {
+    template <int KS, int P0, class B, class H>     // the tile's pieces are P0 .. P0+KS-1 of the slot
+    __device__ __forceinline__ void tile(f32x16& acc, B&& b, H&& hook) {      // hook(IC<ks>) after the MFMA of k-step ks
         constexpr int D = kLdsAhead < KS ? kLdsAhead : KS;
         const unsigned addr = (unsigned)(size_t)(ring + cur * slot_bytes + P0 * 1024 + lane * 16);
         bf16x8 a[D];
         tile_issue<0, D>(a, addr);
-        tile_step<KS, D, 0>(acc, a, addr, b);
+        tile_step<KS, D, 0>(acc, a, addr, b, hook);
     }
     template <int I, int D>
     static __device__ __forceinline__ void tile_issue(bf16x8 (&a)[D], unsigned addr) {
@@ -337,15 +357,16 @@ struct WeightPipe {
             tile_issue<I + 1, D>(a, addr);
         }
     }
-    template <int KS, int D, int ks, class B>
-    static __device__ __forceinline__ void tile_step(f32x16& acc, bf16x8 (&a)[D], unsigned addr, B& b) {
+    template <int KS, int D, int ks, class B, class H>
+    static __device__ __forceinline__ void tile_step(f32x16& acc, bf16x8 (&a)[D], unsigned addr, B& b, H& hook) {
         if constexpr (ks < KS) {
             constexpr int later = (KS - 1 - ks) < (D - 1) ? (KS - 1 - ks) : (D - 1);     // reads issued after piece ks
             asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[ks % D]) : "n"(later));
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D], b(IC<ks>{}), acc, 0, 0, 0);
             if constexpr (ks + D < KS)
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[ks % D]) : "v"(addr), "n"((ks + D) * 1024));
-            tile_step<KS, D, ks + 1>(acc, a, addr, b);
+            hook(IC<ks>{});
+            tile_step<KS, D, ks + 1>(acc, a, addr, b, hook);
         }
     }
 };
@@ -415,7 +436,8 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
     static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
         constexpr int st = decltype(sc)::value;
         constexpr int T0 = st * kTPS, TN = (NT - T0) < kTPS ? (NT - T0) : kTPS;
-        pipe.template prefetch<NERF_FS(STAGE0 + st + kRing - 1).ks>();
+        constexpr int KSN = NERF_FS(STAGE0 + st + kRing - 1).ks, NLD = stage_loads(KSN);
+        pipe.template begin_prefetch<KSN>();      // its loads go out one at a time under the first tile's MFMAs
         static_for<0, TN>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value, nt = T0 + j;
             f32x16 acc;
@@ -425,6 +447,13 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
                 constexpr int ks = decltype(kc)::value;
                 if constexpr (ks < KS_M) return xm[ks];
                 else return xe[ks - KS_M];
+            }, [&](auto kc) __attribute__((always_inline)) {
+                constexpr int ks = decltype(kc)::value;
+                if constexpr (j == 0)
+                    static_for<0, NLD>([&](auto pc) __attribute__((always_inline)) {
+                        constexpr int p = decltype(pc)::value;
+                        if constexpr ((p * KS) / (NLD > 0 ? NLD : 1) == ks) pipe.template prefetch_piece<KSN, p>();
+                    });
             });
             if constexpr (nt > 0) finish(IC<nt - 1>{}, prev);          // runs under this tile's MFMAs
             prev = acc;
@@ -597,7 +626,8 @@ __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[K
     static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
         constexpr int st = decltype(sc)::value;
         constexpr int T0 = st * kTPS, TN = (NT - T0) < kTPS ? (NT - T0) : kTPS;
-        pipe.template prefetch<NERF_BS(STAGE0 + st + kRing - 1).ks>();
+        constexpr int KSN = NERF_BS(STAGE0 + st + kRing - 1).ks, NLD = stage_loads(KSN);
+        pipe.template begin_prefetch<KSN>();      // its loads go out one at a time under the first tile's MFMAs
         if (st == 0) {
 #pragma unroll
             for (int i = 0; i < NW_NEXT; ++i) nextw[i] = next_mask[(b32 * NW_NEXT + i) * 64 + lane];
@@ -611,6 +641,13 @@ __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[K
                 constexpr int ks = decltype(kc)::value;
                 if constexpr (ks < KS_M) return gm[ks];
                 else return ge[ks - KS_M];
+            }, [&](auto kc) __attribute__((always_inline)) {
+                constexpr int ks = decltype(kc)::value;
+                if constexpr (j == 0)
+                    static_for<0, NLD>([&](auto pc) __attribute__((always_inline)) {
+                        constexpr int p = decltype(pc)::value;
+                        if constexpr ((p * KS) / (NLD > 0 ? NLD : 1) == ks) pipe.template prefetch_piece<KSN, p>();
+                    });
             });
             if constexpr (nt > 0) finish(IC<nt - 1>{}, prev);          // runs under this tile's MFMAs
             prev = acc;
