@@ -51,9 +51,11 @@ int nerf_cast_rays(const float* t_vals, const float* origins, const float* direc
 
 /* Integrated positional encoding enc[P, 6L], L = max_deg-min_deg, feature k = l*3+c is
  * exp(-cov_c 4^l / 2) sin(mean_c 2^l), feature 3L+k the same with the angle shifted by
- * fp32(pi/2).                                          reference: util_modules.py:37-44 */
+ * fp32(pi/2).  enc_var[P, 6L] (nullable) receives the per-feature variance
+ * max(0, (1 - exp(-2 cov 4^l) cos(2 angle)) / 2 - enc^2), the second value of the reference's call
+ * (nothing on the render path reads it).               reference: util_modules.py:37-46 */
 int nerf_ipe_encode(const float* mean, const float* cov, int64_t n_points, int min_deg, int max_deg,
-                    float* enc, void* stream);
+                    float* enc, float* enc_var, void* stream);
 
 /* Plain sinusoidal encoding out[P, 6L (+3)]; with append_input != 0 the raw 3-vector is
  * appended (the view-direction feature row).  reference: util_modules.py:49, model.py:125-126 */

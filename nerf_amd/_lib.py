@@ -28,7 +28,7 @@ _SIGS = {
     'nerf_error_string': (c_char_p, [c_int]),
     'nerf_stratified_t': (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P]),
     'nerf_cast_rays': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
-    'nerf_ipe_encode': (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
+    'nerf_ipe_encode': (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     'nerf_pe_encode': (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P]),
     'nerf_sar_raygen': (c_int, [_P, _P, c_int64, _P, _P, _P]),
     'nerf_pinhole_rays': (c_int, [_P, c_int, c_int, c_int, c_float, c_float, c_float, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -90,8 +90,10 @@ __global__ void cast_rays_kernel(const float* __restrict__ t_vals, const float* 
 
 // One thread per (point, level, coordinate); writes the sine feature and its pi/2-shifted twin.
 //                                                                reference: util_modules.py:37-44
+// enc_var (nullable): the variance of each feature, max(0, (1 - exp(-2y) cos 2x) / 2 - enc^2), the second value
+// the reference's call returns.                                      reference: util_modules.py:45
 __global__ void ipe_kernel(const float* __restrict__ mean, const float* __restrict__ cov, int64_t n_points,
-                           int min_deg, int L, float* __restrict__ enc) {
+                           int min_deg, int L, float* __restrict__ enc, float* __restrict__ enc_var) {
     const int F = 3 * L;
     const int64_t total = n_points * F;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -104,8 +106,15 @@ __global__ void ipe_kernel(const float* __restrict__ mean, const float* __restri
         const float x = mean[p * 3 + c] * s1;
         const float y = cov[p * 3 + c] * s2;
         const float damp = expf(-0.5f * y);
-        enc[p * 2 * F + k] = damp * sinf(x);
-        enc[p * 2 * F + F + k] = damp * sinf(x + 1.5707963267948966f);
+        const float xs = x + 1.5707963267948966f;
+        const float e0 = damp * sinf(x), e1 = damp * sinf(xs);
+        enc[p * 2 * F + k] = e0;
+        enc[p * 2 * F + F + k] = e1;
+        if (enc_var != nullptr) {
+            const float damp2 = expf(-2.f * y);
+            enc_var[p * 2 * F + k] = fmaxf(0.f, 0.5f * (1.f - damp2 * cosf(2.f * x)) - e0 * e0);
+            enc_var[p * 2 * F + F + k] = fmaxf(0.f, 0.5f * (1.f - damp2 * cosf(2.f * xs)) - e1 * e1);
+        }
     }
 }
 
@@ -291,12 +300,12 @@ extern "C" int nerf_cast_rays(const float* t_vals, const float* origins, const f
 }
 
 extern "C" int nerf_ipe_encode(const float* mean, const float* cov, int64_t n_points, int min_deg, int max_deg,
-                               float* enc, void* stream) {
+                               float* enc, float* enc_var, void* stream) {
     if (n_points == 0) return NERF_OK;
     NERF_REQUIRE(mean && cov && enc && n_points >= 0 && max_deg > min_deg);
     const int L = max_deg - min_deg;
     hipLaunchKernelGGL(ipe_kernel, dim3(grid_for(n_points * 3 * L)), dim3(256), 0, nerf_stream(stream), mean, cov,
-                       n_points, min_deg, L, enc);
+                       n_points, min_deg, L, enc, enc_var);
     return nerf_launch_status();
 }
 

@@ -29,7 +29,7 @@ class WgradDesc(ctypes.Structure):
 
 
 _lib.register('nerf_mlp_wgrad_multi', c_int, [POINTER(WgradDesc), c_int64, c_int, _P])
-_lib.register('nerf_mlp_wgrad_config', c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)])
+_lib.register('nerf_mlp_wgrad_config', c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)])
 _lib.register('nerf_mlp_wgrad', c_int, [_P, c_int, _P, c_int, c_int64, _P, c_int, c_int, c_int, c_int, _P, c_int, _P])
 
 STREAMED = (['density_net0.%d' % i for i in (0, 2, 4, 6)] + ['density_net1.%d' % i for i in (0, 2, 4, 6)]

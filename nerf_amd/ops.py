@@ -42,11 +42,15 @@ def cast_rays(t_vals, origins, directions, radii, ray_shape):
     return mean, cov
 
 
-def ipe_encode(mean, cov, min_deg, max_deg):
+def ipe_encode(mean, cov, min_deg, max_deg, with_variance=False):
+    """Integrated positional encoding; with `with_variance` also the per-feature variance (util_modules.py:45)."""
     lead = mean.shape[:-1]
     m, c = f32c(mean).reshape(-1, 3), f32c(cov).reshape(-1, 3)
     out = torch.empty(m.shape[0], 6 * (max_deg - min_deg), device=m.device, dtype=torch.float32)
-    check(lib().nerf_ipe_encode(ptr(m), ptr(c), m.shape[0], min_deg, max_deg, ptr(out), stream()))
+    var = torch.empty_like(out) if with_variance else None
+    check(lib().nerf_ipe_encode(ptr(m), ptr(c), m.shape[0], min_deg, max_deg, ptr(out), ptr(var), stream()))
+    if with_variance:
+        return out.reshape(*lead, -1), var.reshape(*lead, -1)
     return out.reshape(*lead, -1)
 
 

@@ -35,8 +35,8 @@ class PositionalEncoding(nn.Module):
     `y` is given, plain sinusoidal encoding otherwise (util_modules.py:29-50).
 
     `scales` is kept as a non-trainable int64 parameter so `state_dict()` carries the same key.
-    The IPE call returns `(encoding, None)`: the reference also computes an encoding variance as
-    the second element, which nothing on the render path reads (model.py:113 takes `[0]`)."""
+    The IPE call returns `(encoding, variance)` like the reference (util_modules.py:44-46); the models'
+    own forward passes take the encoding alone (model.py:113 reads `[0]`) through the fused encoders."""
 
     def __init__(self, min_deg, max_deg):
         super().__init__()
@@ -46,7 +46,7 @@ class PositionalEncoding(nn.Module):
 
     def forward(self, x, y=None):
         if y is not None:
-            return ops.ipe_encode(x, y, self.min_deg, self.max_deg), None
+            return ops.ipe_encode(x, y, self.min_deg, self.max_deg, with_variance=True)
         return ops.pe_encode(x, self.min_deg, self.max_deg)
 
 

@@ -1,8 +1,9 @@
 """Generate the golden fixtures under tests/golden/ by running the upstream reference.
 
-Runs ONLY in the build container (it imports the reference's `utils`, `util_modules`
-and `model` modules from /root/reference behind two stub modules for
-`pytorch_lightning` and `mcubes`, neither of which the render path uses).  The
+Runs ONLY in the build container (it imports the reference's `utils`, `util_modules`,
+`model` and `dataloader` modules from /root/reference behind empty stub modules for the
+packages that are absent here and that the functions called below never touch:
+`pytorch_lightning`, `mcubes`, `sdrparse`, `simulib`, `cv2`).  The
 fixtures (inputs, pre-drawn random tensors, expected outputs and gradients) are plain
 `.npz` data; nothing of the reference's source travels with them.
 
@@ -42,12 +43,20 @@ class LightningModule(nn.Module):
 
 
 pl.LightningModule = LightningModule
+pl.LightningDataModule = type('LightningDataModule', (object,), {'__init__': lambda self, *a, **k: None})
 sys.modules['pytorch_lightning'] = pl
-sys.modules['mcubes'] = types.ModuleType('mcubes')
+# names dataloader.py imports at module level (dataloader.py:3-8); the ray generators never call them
+for _name, _attrs in (('mcubes', ()), ('sdrparse', ('load',)), ('simulib', ()), ('simulib.platform_helper', ('SDRPlatform',)),
+                      ('simulib.simulation_functions', ('azelToVec', 'findPowerOf2')), ('cv2', ())):
+    _m = types.ModuleType(_name)
+    for _a in _attrs:
+        setattr(_m, _a, None)
+    sys.modules[_name] = _m
 
 import utils as R_utils                    # noqa: E402  (reference)
 import util_modules as R_mods              # noqa: E402
 import model as R_model                    # noqa: E402
+import dataloader as R_data                # noqa: E402
 from oracle import nerf_oracle as O        # noqa: E402  (only for init_params / config helpers)
 
 torch.set_num_threads(1)                   # makes the reference's duplicate-bin scatter deterministic
@@ -114,14 +123,14 @@ def gen_posenc():
     out = dict(mean=mean, cov=cov)
     for L in (4, 10, 16):
         pe = R_mods.PositionalEncoding(0, L)
-        out[f'ipe_{L}'] = pe(mean, cov)[0]
+        out[f'ipe_{L}'], out[f'ipe_var_{L}'] = pe(mean, cov)
     pe = R_mods.PositionalEncoding(0, 4)
     v = torch.randn(9, 3, generator=g)
     v = v / v.norm(dim=-1, keepdim=True)
     out['view'] = v
     out['pe_4'] = pe(v)
     pe2 = R_mods.PositionalEncoding(1, 5)
-    out['ipe_1_5'] = pe2(mean, cov)[0]
+    out['ipe_1_5'], out['ipe_var_1_5'] = pe2(mean, cov)
     save('posenc', **out)
 
 
@@ -258,7 +267,8 @@ def gen_nerf_e2e(only=None):
             ('small', dict(hidden=64, num_samples=16, max_deg=4), [16, 16], 48, 11),
             ('small_det', dict(hidden=64, num_samples=16, max_deg=4, randomized=False, white_bkgd=True), [16, 16], 48, 11),
             ('c1', dict(), [64, 64], 64, 12),
-            ('c3', dict(num_samples=128), [64, 128], 64, 13)):
+            ('c3', dict(num_samples=128), [64, 128], 64, 13),
+            ('c3_1k', dict(num_samples=128), [64, 128], 1024, 13)):
         if only is not None and tag not in only:
             continue
         cfg = nerf_cfg(**cfgkw)
@@ -291,10 +301,16 @@ def gen_nerf_e2e(only=None):
             out[f'raw_density_{l}'] = inter['raw_density'][l]
             out[f'raw_rgb_{l}'] = inter['raw_rgb'][l]
         big = cfg.hidden > 64
+        if n > 256:                      # large batches: the per-ray tensors would dominate the file
+            for key in [k for k in out if k.startswith(('t_vals_', 'weights_', 'raw_density_', 'raw_rgb_'))]:
+                del out[key]
         for k, gr in zip(names, grads):
             if big:                      # full-size nets: norms + a strided slice keep the file small
                 out['gnorm_' + k] = gr.norm()
                 out['gslice_' + k] = gr.reshape(-1)[::97][:256]
+                if n > 256:              # a 4096-element sample per tensor: enough for a relative Frobenius error
+                    step = max(1, gr.numel() // 4096)
+                    out['gsample_' + k] = gr.reshape(-1)[::step][:4096]
             else:
                 out['grad_' + k] = gr
         save('nerf_e2e_' + tag, **out)
@@ -450,7 +466,43 @@ def gen_ndc():
          o_ndc=o_ndc, d_ndc=d_ndc, o_ndc_near05=o_ndc2, d_ndc_near05=d_ndc2, img=img, img8=R_utils.to8b(img))
 
 
+def gen_rays():
+    """Ray generation of the dataset classes on bare instances (no files are read): `NeRFDataset.generate_rays`
+    (dataloader.py:103-138) and `LLFF.generate_rays` (dataloader.py:437-460), then `flatten_to_pytorch`
+    (dataloader.py:140-144), i.e. exactly the `[n, .]` float32 tensors a training batch is gathered from."""
+    rng = np.random.default_rng(33)
+    out = {}
+    for tag, cls, C, h, w, focal, near, far in (('pinhole', R_data.NeRFDataset, 3, 11, 13, 17.25, 2., 6.),
+                                               ('pinhole_tele', R_data.NeRFDataset, 2, 5, 8, 1111.0, 2., 6.),
+                                               ('llff', R_data.LLFF, 3, 9, 11, np.float32(13.7), 0., 1.)):
+        c2w = np.zeros((C, 3, 4), np.float32)
+        for c in range(C):
+            q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+            c2w[c, :, :3] = q.astype(np.float32)
+            c2w[c, :, 3] = (rng.standard_normal(3) * 0.3 + [0, 0, 1.5]).astype(np.float32)
+        ds = object.__new__(cls)
+        ds.h, ds.w, ds.focal, ds.near, ds.far, ds.cam_to_world = h, w, focal, near, far, c2w
+        ds.rays, ds.images = None, None
+        ds.generate_rays()
+        ds.flatten_to_pytorch()
+        out.update({f'{tag}_c2w': c2w, f'{tag}_hwf': np.array([h, w, float(focal)], np.float64),
+                    f'{tag}_nearfar': np.array([near, far], np.float64)})
+        for k, v in ds.rays._asdict().items():
+            assert v.dtype == torch.float32 and v.shape[0] == C * h * w
+            out[f'{tag}_{k}'] = v
+    save('rays', **out)
+
+
 if __name__ == '__main__':
+    if _ARGS == ['rays']:
+        gen_rays()
+        sys.exit(0)
+    if _ARGS == ['posenc']:
+        gen_posenc()
+        sys.exit(0)
+    if _ARGS == ['c3_1k']:
+        gen_nerf_e2e(only=('c3_1k',))
+        sys.exit(0)
     if _ARGS == ['ndc']:
         gen_ndc()
         sys.exit(0)
@@ -459,6 +511,7 @@ if __name__ == '__main__':
         gen_nerf_e2e(only=('small_noview',))
         sys.exit(0)
     gen_ndc()
+    gen_rays()
     gen_sample()
     gen_posenc()
     gen_resample()

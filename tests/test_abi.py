@@ -13,6 +13,17 @@ def _declared():
     return sorted(set(re.findall(r'\b(nerf_[a-z0-9_]+)\s*\(', text)))
 
 
+def _prototypes():
+    """name -> number of parameters, for every function prototype in the header."""
+    text = open(os.path.join(ROOT, 'include', 'nerf_amd.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    out = {}
+    for name, args in re.findall(r'\b(nerf_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;', text):
+        args = args.strip()
+        out[name] = 0 if args in ('', 'void') else args.count(',') + 1
+    return out
+
+
 def test_header_symbols_exported():
     from nerf_amd import _lib
     assert os.path.exists(_lib.LIB_PATH), 'run `python -m nerf_amd.build` first'
@@ -31,8 +42,22 @@ def test_bindings_cover_header():
     bound = set(_lib.exported_symbols())
     assert set(_declared()) <= bound, sorted(set(_declared()) - bound)
     L = _lib.lib()
-    assert L.nerf_abi_version() >= 1
+    assert L.nerf_abi_version() >= 2
     assert L.nerf_error_string(-4).decode().startswith('value out of range')
+
+
+def test_binding_argument_counts_match_header():
+    """Every ctypes signature declares exactly as many arguments as the header's prototype (ctypes lets a cdecl
+    call over- or under-supply silently, so drift between the two would otherwise go unseen)."""
+    from nerf_amd import _lib
+    import nerf_amd.ops  # noqa: F401
+    import nerf_amd.mlp  # noqa: F401
+    import nerf_amd.mlp_bf16  # noqa: F401
+    protos = _prototypes()
+    assert set(protos) == set(_declared())
+    for name, n_params in protos.items():
+        restype, argtypes = _lib._SIGS[name]
+        assert len(argtypes) == n_params, (name, len(argtypes), n_params)
 
 
 def test_cpu_tensors_are_refused():

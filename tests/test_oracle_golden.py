@@ -44,6 +44,9 @@ def test_posenc(golden):
         assert torch.equal(O.ipe(mean, cov, 0, L), T(fx[f'ipe_{L}']))
     assert torch.equal(O.ipe(mean, cov, 1, 5), T(fx['ipe_1_5']))
     assert torch.equal(O.pe(T(fx['view']), 0, 4), T(fx['pe_4']))
+    for L in (4, 10, 16):           # the variance the reference's call returns second (util_modules.py:45)
+        assert torch.equal(O.ipe_variance(mean, cov, 0, L), T(fx[f'ipe_var_{L}']))
+    assert torch.equal(O.ipe_variance(mean, cov, 1, 5), T(fx['ipe_var_1_5']))
 
 
 @pytest.mark.parametrize('tag,n_out', [('65_65', 65), ('65_129', 129), ('181_181', 181), ('9_5', 5)])
@@ -180,8 +183,21 @@ def test_losses_lr_and_raygen(golden):
     close(ray_p, T(fx['ray_p']), 1e-6, 1e-2)
 
 
+@pytest.mark.parametrize('tag', ['pinhole', 'pinhole_tele', 'llff'])
+def test_ray_generation_matches_reference(golden, tag):
+    """The NumPy restatements of the dataset classes' ray generation against the reference's own output
+    (`NeRFDataset.generate_rays`, `LLFF.generate_rays` + `flatten_to_pytorch` run on bare instances): bit for bit."""
+    g = golden('rays')
+    h, w, focal = g[tag + '_hwf']
+    near, far = g[tag + '_nearfar']
+    fn = O.ndc_rays if tag == 'llff' else O.pinhole_rays
+    rays = fn(g[tag + '_c2w'], int(h), int(w), float(focal), float(near), float(far))
+    for name, a in zip(('origins', 'directions', 'viewdirs', 'radii', 'lossmult', 'near', 'far'), rays):
+        assert torch.equal(a, T(g[f'{tag}_{name}'])), (tag, name)
+
+
 def test_pinhole_rays_oracle_properties():
-    """No fixture exists for ray generation (see the oracle's docstring): check what the definition implies."""
+    """What the definition of the pinhole rays implies, on an identity pose."""
     import numpy as np
     h, w, focal = 8, 10, 12.0
     c2w = np.eye(4, dtype=np.float32)[None, :3]
