@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """Benchmark of the render hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4]
+
+With --gpus N > 1 and no launcher in the environment, bench.py starts the N ranks itself (one process per GPU
+through torch.distributed.run, RCCL backend) before it touches a GPU, relays rank 0's JSON line and exits
+with the job's status; under an external launcher (WORLD_SIZE set) it is one of the ranks.
 
 Workload ("step"): one full mip-NeRF training step on a batch of synthetic rays already resident in
 HBM -- coarse + fine render at 64+128 samples per ray (stratified sampling, cast + integrated positional
@@ -39,16 +43,76 @@ def make_cfg(precision='bf16'):
                            mlp_precision=precision)
 
 
+PMC_TRAFFIC = 'r02_pmc_traffic.json'
+
+
 def pmc_traffic(kernel, rays=65536):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same workload
-    (profiles/r01_pmc_traffic.json, made by tools/pmc_summary.py); None if absent or for another batch size."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    (profiles/<PMC_TRAFFIC>, made by tools/pmc_summary.py); None if absent or for another batch size."""
+    path = os.path.join(ROOT, 'profiles', PMC_TRAFFIC)
     if rays != 65536 or not os.path.exists(path):
         return None
     for name, rec in json.load(open(path))['kernels'].items():
         if name == kernel or name.startswith(kernel + '<'):
             return rec['traffic_bytes_per_launch']
     return None
+
+
+def make_sar_cfg(precision='bf16'):
+    """The reference's SAR-NeRF hyperparameters (params.yaml:67-93)."""
+    return SimpleNamespace(use_viewdirs=True, randomized=True, ray_shape='cone', num_levels=2, num_samples=180,
+                           hidden=156, density_noise=0.0, density_bias=-1.0, rgb_padding=1e-4, resample_padding=1e-3,
+                           min_deg=0, max_deg=4, viewdirs_min_deg=0, viewdirs_max_deg=4, rays_per_chunk=2048,
+                           total_num_rays=2048, wavelength=0.031228381041666666, coarse_weight_decay=0.01,
+                           lr_init=.5, lr_final=5e-5, lr_delay_steps=5500, lr_delay_mult=0.05, weight_decay=1e-6,
+                           max_steps=2500, white_bkgd=False, mlp_precision=precision, check_range=False)
+
+
+def sar_batch(dev, nsam=2048, nfft=8192, seed=0):
+    """One synthetic pulse: platform at (0, -1000, 500) m, 0.5 m range bins from 900 m, random matched filter and
+    target profile; far = near + mpp (nsam - 2) keeps every range-bin index inside the profile."""
+    g = torch.Generator().manual_seed(seed)
+    near, mpp = torch.tensor([900.]), torch.tensor([0.5])
+    far = near + mpp * (nsam - 2)
+    mfilt = torch.complex(torch.randn(1, nfft, generator=g), torch.randn(1, nfft, generator=g))
+    target = torch.randn(1, nsam, 2, generator=g)
+    ray_o = torch.tensor([[0., -1000., 500.]])
+    return tuple(x.to(dev) if torch.is_tensor(x) else x for x in
+                 (ray_o, None, None, mfilt, torch.tensor([1.12]), near, far, mpp, target))
+
+
+def sar_pulse_step(model, batch, opt, world):
+    """One SAR training step on this rank's own pulse; with several ranks the gradient bucket is averaged (a batch
+    of `world` pulses, where the reference's loader delivers one, params.yaml:99)."""
+    from nerf_amd.train import grad_bucket
+    ray_o, pan, tilt, mfilt, radii, near, far, mpp, target = batch
+    bucket = grad_bucket(model)
+    bucket.zero()
+    pulses = model(ray_o, pan, tilt, mfilt, radii, near, far, target.shape[1], mpp)[0]
+    loss, _ = model.loss_function(pulses, target)
+    (loss / world).backward()
+    bucket.attach()
+    bucket.all_reduce(world)
+    opt.step()
+    model._weights_changed()
+    return loss.detach()
+
+
+def launch_ranks(n, argv):
+    """Start n ranks of this script (one per GPU) and relay their output; nothing here touches a GPU."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and '--rehearse-one-gpu' not in argv:
+        raise SystemExit(f'bench.py --gpus {n}: only {have} HIP device(s) visible')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(budget_rays=192, threads=None):
@@ -101,10 +165,13 @@ def main():
     ap.add_argument('--rehearse-one-gpu', action='store_true',
                     help='N>1 ranks all on cuda:0 over gloo: a rehearsal of the multi-rank code path on a one-GPU box '
                          '(its numbers mean nothing)')
-    ap.add_argument('--workload', default='c3', choices=['c3', 'c2'],
-                    help="c3 (default, the headline metric): full train step; c2: forward-only render (use --rays 1048576)")
+    ap.add_argument('--workload', default='c3', choices=['c3', 'c2', 'c4'],
+                    help="c3 (default, the headline metric): full train step; c2: forward-only render (use --rays 1048576); "
+                         "c4: SAR-NeRF pulse step at the reference's params.yaml sizes (2048 rays x 180+180 samples)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:       # no launcher around us: be the launcher
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -112,7 +179,7 @@ def main():
         raise SystemExit('bench.py needs a HIP device (the render path has no CPU fallback)')
     if args.rehearse_one_gpu:
         import faulthandler
-        faulthandler.dump_traceback_later(60, exit=True)        # a rehearsal that hangs says where
+        faulthandler.dump_traceback_later(150, exit=True)        # a rehearsal that hangs says where
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -125,24 +192,34 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from nerf_amd import profiling
-    from nerf_amd.model import MipNeRF
+    from nerf_amd.model import MipNeRF, SARNeRF
     from nerf_amd.train import nerf_train_step, synthetic_rays
 
     torch.manual_seed(0)
-    cfg = make_cfg(args.precision)
-    model = MipNeRF(cfg).to(dev).train()
+    sar = args.workload == 'c4'
+    cfg = make_sar_cfg(args.precision) if sar else make_cfg(args.precision)
+    model = (SARNeRF(cfg) if sar else MipNeRF(cfg)).to(dev).train()
     if world > 1:                                    # identical replicas
         for p in model.parameters():
             dist.broadcast(p.data, 0)
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=cfg.lr_init, weight_decay=cfg.weight_decay, fused=True)
-    rays, pixels = synthetic_rays(args.rays, dev, seed=1234 + rank)
-    mask_sum = rays.lossmult.sum() * world
+    if sar:
+        # one pulse per step and rank (ranks take different pulses: weak scaling); the reference's lr_init of 0.5
+        # diverges on synthetic targets within a few steps, so the timed steps use a small fixed rate
+        args.rays = cfg.total_num_rays
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=cfg.weight_decay, fused=True)
+        batch = sar_batch(dev, seed=100 + rank)
+    else:
+        opt = torch.optim.AdamW(params, lr=cfg.lr_init, weight_decay=cfg.weight_decay, fused=True)
+        rays, pixels = synthetic_rays(args.rays, dev, seed=1234 + rank)
+        mask_sum = rays.lossmult.sum() * world
 
     def step():
         if args.workload == 'c2':                   # coarse+fine render only, nothing saved for a backward pass
             with torch.no_grad():
                 return model(rays)[0].sum()
+        if sar:                                     # every rank renders a whole pulse of its own; gradients are averaged
+            return sar_pulse_step(model, batch, opt, world)
         return nerf_train_step(model, rays, pixels, opt, chunk=args.chunk, world_size=world, global_mask_sum=mask_sum)
 
     def fence():
@@ -170,11 +247,14 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = args.rays * world * args.steps / dt
         out = {
-            'metric': 'rays/sec fwd+bwd (64+128 samples/ray)' if args.workload == 'c3' else 'rays/sec fwd (64+128 samples/ray)',
+            'metric': {'c3': 'rays/sec fwd+bwd (64+128 samples/ray)', 'c2': 'rays/sec fwd (64+128 samples/ray)',
+                       'c4': 'rays/sec fwd+bwd (SAR pulse, 180+180 samples/ray)'}[args.workload],
             'value': value, 'unit': 'rays/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
-            'config': {'workload': ('C3: full NeRF train step (fwd+bwd+AdamW)' if args.workload == 'c3' else
+            'config': {'workload': 'C4: SAR-NeRF pulse step (fwd+bwd+AdamW), 2048 rays x (180+180) samples, H=156, '
+                                   'W=180, L=4/4, nsam 2048, Nfft 8192' if sar else
+                                   ('C3: full NeRF train step (fwd+bwd+AdamW)' if args.workload == 'c3' else
                                     'C2: forward-only hierarchical render') + ', coarse 64 + fine 128 samples/ray, '
                                    '8x256 MLP (colour width 128), L=10/4 posenc',
                        'rays_per_step_per_gpu': args.rays, 'global_rays_per_step': args.rays * world,

@@ -124,7 +124,7 @@ int nerf_composite_fwd(const float* rgb, const float* density, const float* t_va
 
 /* Gradient of the above w.r.t. rgb and density inputs (w.r.t. the raw inputs when the
  * activation is fused).  g_distance / g_acc may be NULL (= zero).  Where the reference's
- * autograd yields NaN (acc == 0 with a distance gradient) this returns 0. */
+ * autograd yields NaN (acc == 0 with a distance gradient) this returns 0.  num_samples <= 2048. */
 int nerf_composite_bwd(const float* rgb, const float* density, const float* t_vals, const float* dirs,
                        const float* g_comp_rgb, const float* g_distance, const float* g_acc,
                        int64_t n_rays, int num_samples, int white_bkgd, const nerf_activation* act,
@@ -148,10 +148,13 @@ int nerf_scatter_fwd(const float* rgb, const float* angle, const float* density,
                      void* stream);
 
 /* Gradient of nerf_scatter_fwd w.r.t. rgb, angle, density given g_pulse[nsam,2]; every ray of
- * a bin receives the bin's gradient (reference autograd behaviour for the indexed +=). */
+ * a bin receives the bin's gradient (reference autograd behaviour for the indexed +=).
+ * g_distance[R] / g_acc[R] (nullable = zero) are the gradients w.r.t. the returned distance and acc
+ * outputs themselves (utils.py:380 returns both).  num_samples <= 2048. */
 int nerf_scatter_bwd(const float* rgb, const float* angle, const float* density, const float* power,
                      const float* t_vals, const float* dirs, const float* g_pulse,
-                     const int32_t* ray_bin, const float* comp, const float* distance, int64_t n_rays,
+                     const int32_t* ray_bin, const float* comp, const float* distance,
+                     const float* g_distance, const float* g_acc, int64_t n_rays,
                      int num_samples, int nsam, float wavelength, const nerf_activation* act,
                      float* g_rgb, float* g_angle, float* g_density, void* stream);
 

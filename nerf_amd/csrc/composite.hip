@@ -369,6 +369,7 @@ __global__ void scatter_bwd_kernel(const float* __restrict__ rgb, const float* _
                                    const float* __restrict__ t_vals, const float* __restrict__ dirs,
                                    const float* __restrict__ g_pulse, const int32_t* __restrict__ ray_bin,
                                    const float* __restrict__ comp, const float* __restrict__ distance,
+                                   const float* __restrict__ g_distance, const float* __restrict__ g_accp,
                                    int64_t n_rays, int S, int nsam, float wavelength, ActParams act,
                                    float* __restrict__ g_rgb, float* __restrict__ g_angle,
                                    float* __restrict__ g_density) {
@@ -397,14 +398,20 @@ __global__ void scatter_bwd_kernel(const float* __restrict__ rgb, const float* _
     sar_reflect_bwd(c, ang, distance[ray], power[ray], d, wavelength, g_re, g_im, gc, gang, &g_dist);
     bool passes = false;
     (void)expected_distance(r.num, r.acc, t[0], t[S], &passes);
+    // the returned distance feeds the reflectance model and is an output of its own; acc is an output only
+    if (g_distance != nullptr) g_dist += g_distance[ray];
     const float g_d = passes ? g_dist : 0.f;
+    const float g_acc = g_accp != nullptr ? g_accp[ray] : 0.f;
     composite_ray_bwd<2>(rgb + ray * S * 3, angle + ray * S * 2, density + ray * S, t, dnorm, S, lane, act, w_lds,
-                         te_lds, gc, gang, SAR_ANGLE_SCALE, 0.f, g_d, r.num / r.acc, r.acc, g_rgb + ray * S * 3,
+                         te_lds, gc, gang, SAR_ANGLE_SCALE, g_acc, g_d, r.num / r.acc, r.acc, g_rgb + ray * S * 3,
                          g_angle + ray * S * 2, g_density + ray * S);
 }
 
 // ------------------------------------------------------------------------------------------
 static const int kWavesPerBlock = 4;
+// The backward kernels keep 2 floats per sample and wave in dynamic LDS: 32 bytes x S per workgroup, within the
+// 64 KiB a launch may request without raising the kernel's dynamic-LDS attribute.
+static const int kMaxBwdSamples = 2048;
 
 extern "C" int nerf_composite_fwd(const float* rgb, const float* density, const float* t_vals, const float* dirs,
                                   int64_t n_rays, int num_samples, int white_bkgd, const nerf_activation* act,
@@ -425,7 +432,7 @@ extern "C" int nerf_composite_bwd(const float* rgb, const float* density, const 
     if (n_rays == 0) return NERF_OK;
     NERF_REQUIRE(rgb && density && t_vals && dirs && g_comp_rgb && g_rgb && g_density && n_rays >= 0 &&
                  num_samples >= 1);
-    if (num_samples > 4096) return NERF_ERR_SIZE;
+    if (num_samples > kMaxBwdSamples) return NERF_ERR_SIZE;
     const size_t lds = (size_t)kWavesPerBlock * 2 * num_samples * sizeof(float);
     hipLaunchKernelGGL(composite_bwd_kernel, dim3(nerf_blocks(n_rays, kWavesPerBlock)), dim3(64 * kWavesPerBlock),
                        lds, nerf_stream(stream), rgb, density, t_vals, dirs, g_comp_rgb, g_distance, g_acc, n_rays,
@@ -459,17 +466,19 @@ extern "C" int nerf_scatter_fwd(const float* rgb, const float* angle, const floa
 
 extern "C" int nerf_scatter_bwd(const float* rgb, const float* angle, const float* density, const float* power,
                                 const float* t_vals, const float* dirs, const float* g_pulse,
-                                const int32_t* ray_bin, const float* comp, const float* distance, int64_t n_rays,
+                                const int32_t* ray_bin, const float* comp, const float* distance,
+                                const float* g_distance, const float* g_acc, int64_t n_rays,
                                 int num_samples, int nsam, float wavelength, const nerf_activation* act,
                                 float* g_rgb, float* g_angle, float* g_density, void* stream) {
     if (n_rays == 0) return NERF_OK;
     NERF_REQUIRE(rgb && angle && density && power && t_vals && dirs && g_pulse && ray_bin && comp && distance &&
                  g_rgb && g_angle && g_density);
     NERF_REQUIRE(n_rays >= 0 && num_samples >= 1 && nsam >= 1 && wavelength > 0.f);
-    if (num_samples > 4096) return NERF_ERR_SIZE;
+    if (num_samples > kMaxBwdSamples) return NERF_ERR_SIZE;
     const size_t lds = (size_t)kWavesPerBlock * 2 * num_samples * sizeof(float);
     hipLaunchKernelGGL(scatter_bwd_kernel, dim3(nerf_blocks(n_rays, kWavesPerBlock)), dim3(64 * kWavesPerBlock), lds,
                        nerf_stream(stream), rgb, angle, density, power, t_vals, dirs, g_pulse, ray_bin, comp,
-                       distance, n_rays, num_samples, nsam, wavelength, make_act(act), g_rgb, g_angle, g_density);
+                       distance, g_distance, g_acc, n_rays, num_samples, nsam, wavelength, make_act(act), g_rgb,
+                       g_angle, g_density);
     return nerf_launch_status();
 }

@@ -17,7 +17,8 @@ constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int LDS_LD = BM + 4;   // row pad: consecutive k rows land on different banks for the staging writes
 
 // C[M,N] = act(A[M,K] * B[K,N] + bias[N]); A and B are addressed through (row, col) element
-// strides, so transposed operands need no copy.  grid = (ceil(N/BN), ceil(M/BM), split_k); with
+// strides, so transposed operands need no copy.  grid = (ceil(M/BM), ceil(N/BN), split_k) -- the row tiles
+// are on grid.x, the only grid axis that can hold millions of them; with
 // split_k > 1 each z-slice owns a K range and adds its partial tile into C with fp32 atomics
 // (C must be zeroed by the caller; bias/activation are not allowed in that mode).
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int64_t a_rs, int64_t a_cs,
@@ -30,8 +31,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;            // 2 x 2 waves, 64 x 64 outputs each
-    const int64_t m0 = (int64_t)blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
     const int64_t k_begin = (int64_t)blockIdx.z * k_per_split;
     const int64_t k_end = (k_begin + k_per_split < K) ? k_begin + k_per_split : K;
 
@@ -194,11 +195,11 @@ extern "C" int nerf_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const f
     NERF_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && split_k >= 1);
     NERF_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_SIGMOID);
     if (split_k > 1) NERF_REQUIRE(bias == nullptr && act == ACT_NONE);
-    if ((M + BM - 1) / BM > 65535 * 32) return NERF_ERR_SIZE;
     int64_t kps = (K + split_k - 1) / split_k;
     kps = ((kps + BK - 1) / BK) * BK;
-    const unsigned gz = (unsigned)((K + kps - 1) / kps);
-    dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), gz);
+    const int64_t gx = (M + BM - 1) / BM, gy = (N + BN - 1) / BN, gz = (K + kps - 1) / kps;
+    if (gx > 0x7fffffffLL || gy > 65535 || gz > 65535) return NERF_ERR_SIZE;       // HIP grid limits
+    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)gz);
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, nerf_stream(stream), A, a_rs, a_cs, B, b_rs, b_cs, bias, C,
                        ldc, M, N, K, act, split_k > 1 ? 1 : 0, kps);
     return nerf_launch_status();

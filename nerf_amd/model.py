@@ -321,6 +321,9 @@ class SARNeRF(_RenderModule):
         With `world_size > 1` (torch.distributed initialised) the ray chunks are dealt round-robin to the ranks
         and the per-level range profiles are SUM-all-reduced ahead of the matched filter: the pulses are those of
         the one-device loop; distance / acc are those of this rank's last chunk.
+        A ray whose expected distance lies beyond the last pulse bin raises IndexError, as the reference's indexed
+        write does (utils.py:379); the check reads one status word back per call (one stream synchronisation) and
+        `config.check_range = False` switches it off (such rays are then dropped from the profile).
         -> pulses [L,1,nsam,2], distance [L,1,R], acc [L,1,R]"""
         cfg = self.config
         dev = self.device
@@ -337,6 +340,7 @@ class SARNeRF(_RenderModule):
         comp = [torch.zeros(nsam, 2, device=dev) for _ in range(L)]
         distances, accs = [None] * L, [None] * L
         raw_rgb = raw_density = None
+        statuses = []
         for c in range(self.num_ray_iters):
             if az_el is not None:
                 az, el = az_el[c]
@@ -383,6 +387,10 @@ class SARNeRF(_RenderModule):
                 comp[l] = comp[l] + pulse
                 distances[l] = distance
                 accs[l] = acc
+                statuses.append(status)
+        if statuses and getattr(cfg, 'check_range', True) and int(torch.cat(statuses).min()) != 0:
+            raise IndexError('range bin index out of bounds: a ray distance lies beyond the last pulse bin '
+                             '(far > near + (nsam - 1) * mpp)')
         mf = mfilt.to(dev)
         outs = []
         if world_size > 1:

@@ -216,10 +216,13 @@ class _Scatter(torch.autograd.Function):
         rgb, angle, density, power, t_vals, dirs, ray_bin, comp, dist = ctx.saved_tensors
         r, s, nsam, wl, act = ctx.meta
         g_pulse = f32c(g_pulse) if g_pulse is not None else torch.zeros(nsam, 2, device=rgb.device)
+        g_dist = f32c(g_dist).reshape(-1) if g_dist is not None else None
+        g_acc = f32c(g_acc).reshape(-1) if g_acc is not None else None
         g_rgb, g_ang, g_den = torch.empty_like(rgb), torch.empty_like(angle), torch.empty_like(density)
         check(lib().nerf_scatter_bwd(ptr(rgb), ptr(angle), ptr(density), ptr(power), ptr(t_vals), ptr(dirs),
-                                     ptr(g_pulse), ptr(ray_bin, torch.int32), ptr(comp), ptr(dist), r, s, nsam, wl,
-                                     _act(*act), ptr(g_rgb), ptr(g_ang), ptr(g_den), stream()))
+                                     ptr(g_pulse), ptr(ray_bin, torch.int32), ptr(comp), ptr(dist), ptr(g_dist),
+                                     ptr(g_acc), r, s, nsam, wl, _act(*act), ptr(g_rgb), ptr(g_ang), ptr(g_den),
+                                     stream()))
         return g_rgb, g_ang, g_den, None, None, None, None, None, None
 
 

@@ -21,29 +21,68 @@ def synthetic_rays(n, device, seed=0, normalize=True):
     return namedtuple_map(lambda t: t.to(device), rays), pixels.to(device)
 
 
-def flat_grads(params):
-    """One contiguous fp32 bucket holding every gradient (a single collective per step)."""
-    return torch.cat([p.grad.reshape(-1) for p in params])
+class GradBucket:
+    """One persistent, contiguous buffer (the parameters' dtype, fp32 for the render models) that holds every gradient: each parameter's `.grad` is a view into
+    it, so the weight-gradient kernels accumulate straight into the bucket and the step needs exactly one
+    collective on it, with no gather before and no scatter after.  Views start on 256-byte boundaries (the
+    padding stays zero and rides along in the collective)."""
+
+    ALIGN = 64          # floats
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += -(-p.numel() // self.ALIGN) * self.ALIGN
+        dev = self.params[0].device if self.params else torch.device('cpu')
+        dtype = self.params[0].dtype if self.params else torch.float32
+        self.flat = torch.zeros(n, dtype=dtype, device=dev)
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, self.params)]
+        self.attach()
+
+    def attach(self):
+        """(Re)install the views as the parameters' `.grad` (an optimizer's `zero_grad(set_to_none=True)` or a
+        backward pass into a parameter without a gradient replaces them)."""
+        for p, v in zip(self.params, self.views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
+
+    def zero(self):
+        self.attach()
+        self.flat.zero_()
+
+    def all_reduce(self, world_size, async_op=False):
+        """SUM over ranks, in place (RCCL on GPUs, gloo on CPU); returns the work handle when `async_op`."""
+        if world_size <= 1:
+            return None
+        return _all_reduce_sum(self.flat, async_op=async_op)
 
 
-def scatter_flat_grads(params, flat):
-    off = 0
-    for p in params:
-        n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p))
-        off += n
+def grad_bucket(model_or_params):
+    """The gradient bucket of a model (cached on it) or of a parameter list."""
+    if isinstance(model_or_params, torch.nn.Module):
+        params = [p for p in model_or_params.parameters() if p.requires_grad]
+        b = getattr(model_or_params, '_grad_bucket', None)
+        if (b is None or len(b.params) != len(params) or any(x is not y for x, y in zip(b.params, params))
+                or (params and b.flat.device != params[0].device)):
+            b = GradBucket(params)
+            model_or_params._grad_bucket = b
+        return b
+    return GradBucket(list(model_or_params))
 
 
 def allreduce_grads(params, world_size):
-    """SUM-all-reduce of the flattened gradient bucket (RCCL on GPUs, gloo on CPU)."""
+    """SUM-all-reduce of the gradients of `params` as one flat bucket.  Gradients that already are views of a
+    `GradBucket` are reduced in place; otherwise they are moved into a fresh bucket first."""
     if world_size <= 1:
         return
-    flat = flat_grads(params)
-    _all_reduce_sum(flat)
-    scatter_flat_grads(params, flat)
+    GradBucket([p for p in params if p.grad is not None or p.requires_grad]).all_reduce(world_size)
 
 
-def _all_reduce_sum(t):
+def _all_reduce_sum(t, async_op=False):
     """In-place SUM all-reduce.  RCCL reduces device buffers directly; under gloo (CPU rehearsals of the multi-rank
     path) a device tensor is staged through host memory: gloo's own device path was seen to hang on a 2.4 MB
     bucket with two ranks on one GPU."""
@@ -52,8 +91,8 @@ def _all_reduce_sum(t):
         host = t.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM)
         t.copy_(host)
-    else:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
 def shard_range(n, rank, world_size):
@@ -69,14 +108,14 @@ def nerf_train_step(model, rays, pixels, optimizer, chunk=8192, world_size=1, gl
     The loss is sum(mask * err^2) / sum(mask) over the GLOBAL batch (util_modules.py:65), so each
     chunk contributes its masked squared-error sum divided by the global mask sum; gradients then
     add up across chunks and ranks."""
-    params = [p for p in model.parameters() if p.requires_grad]
+    bucket = grad_bucket(model)
     n = rays.origins.shape[0]
-    if global_mask_sum is None:
-        global_mask_sum = rays.lossmult.sum() * world_size
-    optimizer.zero_grad(set_to_none=False)
-    for p in params:
-        if p.grad is None:
-            p.grad = torch.zeros_like(p)
+    if global_mask_sum is None:             # the denominator of the reference loss is the mask sum of the WHOLE batch
+        global_mask_sum = rays.lossmult.sum()
+        if world_size > 1:                  # shards may be unequal (short last batch): add them up, do not scale
+            global_mask_sum = global_mask_sum.clone()
+            _all_reduce_sum(global_mask_sum)
+    bucket.zero()
     total = torch.zeros((), device=rays.origins.device)
     cwd = model.loss_function.coarse_weight_decay
     import contextlib
@@ -92,7 +131,10 @@ def nerf_train_step(model, rays, pixels, optimizer, chunk=8192, world_size=1, gl
             loss = cwd * sq[:-1].sum() + sq[-1]
             loss.backward()
             total += loss.detach()
-    allreduce_grads(params, world_size)
+    bucket.attach()
+    work = bucket.all_reduce(world_size, async_op=True)
+    if work is not None:
+        work.wait()             # orders the collective ahead of the optimizer kernels on the current stream
     optimizer.step()
     if scheduler is not None:
         scheduler.step()
@@ -129,17 +171,15 @@ def sar_train_step(model, batch, optimizer, rank=0, world_size=1, scheduler=None
     per-pulse std, every rank evaluates the same loss, and the weight gradients -- partial sums over each
     rank's chunks -- are SUM-all-reduced in one flat bucket."""
     ray_o, pan, tilt, mfilt, radii, near, far, mpp, pulse_data = batch
-    params = [p for p in model.parameters() if p.requires_grad]
-    optimizer.zero_grad(set_to_none=False)
-    for p in params:
-        if p.grad is None:
-            p.grad = torch.zeros_like(p)
+    bucket = grad_bucket(model)
+    bucket.zero()
     pulses = model(ray_o, pan, tilt, mfilt, radii, near, far, pulse_data.shape[1], mpp, rank=rank,
                    world_size=world_size, **draws)[0]
     loss, _ = model.loss_function(pulses, pulse_data.to(pulses.device))
     if loss.requires_grad:              # a rank that was dealt no chunk has nothing to differentiate
         loss.backward()
-    allreduce_grads(params, world_size)
+    bucket.attach()
+    bucket.all_reduce(world_size)
     optimizer.step()
     if scheduler is not None:
         scheduler.step()

@@ -128,3 +128,119 @@ def test_training_fits_a_scene_from_device_generated_batches():
     assert all(l == l for l in losses)                   # finite
     assert sum(losses[-10:]) < 0.5 * sum(losses[:10]), (losses[:3], losses[-3:])
     assert after > before + 4.0, (before, after)
+
+
+def _sar_cfg(precision, wavelength, R=2048):
+    """The reference's SAR-NeRF hyperparameters (params.yaml:67-93): R rays per chunk, one chunk per pulse."""
+    return SimpleNamespace(use_viewdirs=True, randomized=True, ray_shape='cone', num_levels=2, num_samples=180,
+                           hidden=156, density_noise=0.0, density_bias=-1.0, rgb_padding=1e-4, resample_padding=1e-3,
+                           min_deg=0, max_deg=4, viewdirs_min_deg=0, viewdirs_max_deg=4, rays_per_chunk=R,
+                           total_num_rays=R, wavelength=wavelength, coarse_weight_decay=0.01, lr_init=.5,
+                           lr_final=5e-5, lr_delay_steps=5500, lr_delay_mult=0.05, weight_decay=1e-6, max_steps=2500,
+                           white_bkgd=False, mlp_precision=precision)
+
+
+def _sar_pulse(R, nsam=2048, nfft=8192, seed=0):
+    from oracle import nerf_oracle as O
+    g = torch.Generator().manual_seed(seed)
+    near, mpp = torch.tensor([900.]), torch.tensor([0.5])
+    far = near + mpp * (nsam - 2)
+    mfilt = torch.complex(torch.randn(1, nfft, generator=g), torch.randn(1, nfft, generator=g))
+    target = torch.randn(1, nsam, 2, generator=g)
+    az_el = [(torch.randn(R, generator=g) * O.SAR_AZ_SIGMA, torch.randn(R, generator=g) * O.SAR_EL_SIGMA)]
+    t_rand = [torch.rand(R, 181, generator=g)]
+    u_rand = [torch.empty(R, 181).uniform_(0, 1 / 181 - O.EPS32, generator=g)]
+    return dict(ray_o=torch.tensor([[0., -1000., 500.]]), mfilt=mfilt, radii=torch.tensor([1.12]), near=near, far=far,
+                mpp=mpp, nsam=nsam, target=target, az_el=az_el, t_rand=t_rand, u_rand=u_rand)
+
+
+def _sar_run(m, b):
+    cu = lambda xs: [x.cuda() for x in xs]
+    m.zero_grad(set_to_none=True)
+    pulses, dist, acc = m(b['ray_o'], None, None, b['mfilt'], b['radii'], b['near'], b['far'], b['nsam'], b['mpp'],
+                          az_el=b['az_el'], t_rand=cu(b['t_rand']), u_rand=cu(b['u_rand']))
+    loss = m.loss_function(pulses, b['target'].cuda())[0]
+    loss.backward()
+    grads = {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.requires_grad}
+    return pulses.detach(), dist.detach(), acc.detach(), float(loss), grads
+
+
+def test_c4_sar_step_at_reference_sizes():
+    """`SARNeRF` forward + backward at the sizes of the reference's SAR configuration (params.yaml:67-93: 2048 rays,
+    180 + 180 samples, hidden 156, colour width 180, L = 4/4; 2048 range bins, 8192-point matched filter).
+
+    (1) Against the oracle at 96 rays (what it finishes in seconds), same network sizes, 40 m wavelength (a
+        well-conditioned fp32 phase): pulses, distance, acc, loss within the 2e-2 gate of the bf16 MLP.
+    (2) At the full 2048 rays the exact-fp32 path (1e-4 parity with the oracle) stands in for it: the bf16 chain
+        must give the same pulses, distances, accs and loss to 2e-2 and gradients of the same direction and size.
+    (3) At the radar's 3.1 cm wavelength: range-compressed profiles normalised to unit spread per level, acc in
+        [0, 1], distances inside [near, far], all 28 gradients finite and non-zero."""
+    from oracle import nerf_oracle as O
+    from nerf_amd.model import SARNeRF
+    from tests.conftest import relerr
+    # (1) oracle, reduced ray count
+    R = 96
+    b = _sar_pulse(R, seed=1)
+    cfg = _sar_cfg('bf16', 40.0, R)
+    p = O.init_params(cfg, sar=True, seed=7)
+    m = SARNeRF(cfg).cuda().train()
+    m.load_state_dict(p, strict=False)
+    ref_p, ref_d, ref_a, _ = O.sar_render(p, b['ray_o'], b['az_el'], b['mfilt'], 1.12, 900., float(b['far'][0]), b['nsam'],
+                                          0.5, cfg, b['t_rand'], [{1: u} for u in b['u_rand']])
+    ref_loss = float(O.sar_loss(ref_p, b['target'], cfg.coarse_weight_decay)[0])
+    got_p, got_d, got_a, loss, _ = _sar_run(m, b)
+    assert relerr(got_a.cpu(), ref_a) < 2e-2 and relerr(got_d.cpu(), ref_d) < 2e-2
+    assert relerr(got_p.cpu()[0], ref_p[0]) < 2e-2
+    assert abs(loss - ref_loss) < 2e-2 * abs(ref_loss)
+
+    # (2) full size, fp32 path as the stand-in oracle
+    R = 2048
+    b = _sar_pulse(R, seed=2)
+    outs = {}
+    for prec in ('fp32', 'bf16'):
+        cfg = _sar_cfg(prec, 40.0, R)
+        m = SARNeRF(cfg).cuda().train()
+        m.load_state_dict(O.init_params(cfg, sar=True, seed=7), strict=False)
+        outs[prec] = _sar_run(m, b)
+    f, h = outs['fp32'], outs['bf16']
+    assert relerr(h[2], f[2]) < 2e-2 and relerr(h[1], f[1]) < 2e-2
+    assert relerr(h[0][0], f[0][0]) < 2e-2
+    assert abs(h[3] - f[3]) < 2e-2 * abs(f[3])
+    gf = torch.cat([f[4][k].reshape(-1) for k in sorted(f[4])])
+    gh = torch.cat([h[4][k].reshape(-1) for k in sorted(f[4])])
+    cos = float((gf * gh).sum() / (gf.norm() * gh.norm()))
+    print('c4 full size: bf16 vs fp32 gradient cosine %.4f, norm ratio %.4f' % (cos, float(gh.norm() / gf.norm())))
+    assert cos > 0.9 and abs(float(gh.norm() / gf.norm()) - 1) < 0.2
+
+    # (3) the radar's wavelength
+    cfg = _sar_cfg('bf16', 0.031228381041666666, R)
+    m = SARNeRF(cfg).cuda().train()
+    m.load_state_dict(O.init_params(cfg, sar=True, seed=7), strict=False)
+    pulses, dist, acc, loss, grads = _sar_run(m, b)
+    assert pulses.shape == (2, 1, 2048, 2) and dist.shape == (2, 1, R) and acc.shape == (2, 1, R)
+    z = torch.view_as_complex(pulses.contiguous())
+    assert torch.allclose(torch.std(z, dim=-1), torch.ones(2, 1, device='cuda'), atol=1e-4)
+    assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-6
+    assert float(dist.min()) >= 900.0 - 1e-3 and float(dist.max()) <= float(b['far'][0]) + 1e-3
+    assert loss == loss and len(grads) == 28
+    for k, g in grads.items():
+        assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0, k
+
+
+def test_sar_forward_raises_beyond_the_last_range_bin():
+    """A far plane beyond the last pulse bin: the reference's indexed write raises IndexError (utils.py:379), and so
+    does the model's forward; `check_range = False` drops such rays silently instead."""
+    from nerf_amd.model import SARNeRF
+    R = 256
+    b = _sar_pulse(R, nsam=64, nfft=128, seed=3)
+    b['far'] = b['near'] + 400.0                   # bins end at near + 31.5 m
+    b['t_rand'], b['u_rand'] = None, None
+    cfg = _sar_cfg('bf16', 0.03, R)
+    cfg.randomized = False
+    m = SARNeRF(cfg).cuda().train()
+    args = (b['ray_o'], None, None, b['mfilt'], b['radii'], b['near'], b['far'], b['nsam'], b['mpp'])
+    with pytest.raises(IndexError):
+        m(*args, az_el=b['az_el'])
+    cfg.check_range = False
+    out = m(*args, az_el=b['az_el'])
+    assert bool(torch.isfinite(out[1]).all())

@@ -196,10 +196,18 @@ def test_mlp_gradients_vs_oracle(tag, kw, S, n):
         assert abs(float(gk.norm() / gr.norm()) - 1) < 5e-2, (tag, k)
 
 
-@pytest.mark.parametrize('tag', ['small', 'small_det', 'c1', 'c3'])
+# Relative Frobenius error ||g - ref|| / ||ref|| allowed per gradient tensor against the reference's autograd
+# (fp32).  The bf16 MLP gate is 2e-2; it is met on the 1024-ray batch, where a ReLU decision flipped by bf16
+# rounding (an O(1) change of one sample's contribution) is one of ~200 000 samples.  The 48- and 64-ray fixtures
+# hold 800 - 12 000 samples, so single flips show: their bound is the measured figure with headroom.
+GRAD_GATE = {'small': 6e-2, 'small_det': 6e-2, 'c1': 6e-2, 'c3': 6e-2, 'c3_1k': 2e-2}
+
+
+@pytest.mark.parametrize('tag', ['small', 'small_det', 'c1', 'c3', 'c3_1k'])
 def test_nerf_end_to_end_bf16(golden, tag):
-    """Two-level render with the bf16 MLP against the reference fixtures: colour, depth, acc, loss and all
-    parameter gradients within 2e-2 (the resampled fine level sees bf16-perturbed coarse weights)."""
+    """Two-level render with the bf16 MLP against the reference fixtures: colour, depth, acc, loss within 2e-2 (the
+    resampled fine level sees bf16-perturbed coarse weights); every parameter gradient by relative Frobenius error
+    (full tensors for the small nets, a strided 256- or 4096-element sample per tensor for the 8x256 nets)."""
     from nerf_amd.model import MipNeRF
     from nerf_amd.utils import Rays
     fx = golden('nerf_e2e_' + tag)
@@ -220,15 +228,25 @@ def test_nerf_end_to_end_bf16(golden, tag):
     loss, _ = m.loss_function(rgb, T(fx['target']).cuda(), rays.lossmult)
     assert abs(float(loss) - float(fx['loss'])) < 2e-2 * abs(float(fx['loss']))
     loss.backward()
+    errs = {}
     for k, v in m.named_parameters():
         if k.endswith('scales'):
             continue
+        g = v.grad.cpu()
         if 'grad_' + k in fx:
-            ref = T(fx['grad_' + k])
-            assert cosine(v.grad.cpu(), ref) > 0.99, k
-            assert abs(float(v.grad.norm() / ref.norm()) - 1) < 3e-2, k
+            errs[k] = fro(g, T(fx['grad_' + k]))
         else:
-            assert abs(float(v.grad.norm()) - float(fx['gnorm_' + k])) < 3e-2 * float(fx['gnorm_' + k]), k
+            assert abs(float(g.norm()) - float(fx['gnorm_' + k])) < 3e-2 * float(fx['gnorm_' + k]), k
+            if 'gsample_' + k in fx:
+                ref = T(fx['gsample_' + k])
+                errs[k] = fro(g.reshape(-1)[::max(1, g.numel() // 4096)][:4096], ref)
+            else:
+                errs[k] = fro(g.reshape(-1)[::97][:256], T(fx['gslice_' + k]))
+    print(tag, 'relative Frobenius error per gradient:', {k: round(e, 4) for k, e in errs.items()})
+    print(tag, 'worst %.4f  median %.4f' % (max(errs.values()), sorted(errs.values())[len(errs) // 2]))
+    assert len(errs) == 24
+    for k, e in errs.items():
+        assert e < GRAD_GATE[tag], (tag, k, e)
 
 
 def test_packed_weights_follow_parameter_updates():

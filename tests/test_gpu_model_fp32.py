@@ -72,6 +72,9 @@ def _rays(fx):
     return Rays(*(G(fx['ray_' + k]) for k in ('origins', 'directions', 'viewdirs', 'radii', 'lossmult', 'near', 'far')))
 
 
+GRAD_GATE_FP32 = 1e-3        # of the tensor's largest entry
+
+
 @pytest.mark.parametrize('tag', ['small', 'small_det', 'small_noview', 'c1', 'c3'])
 def test_nerf_end_to_end_golden(golden, tag):
     fx = golden('nerf_e2e_' + tag)
@@ -93,6 +96,7 @@ def test_nerf_end_to_end_golden(golden, tag):
     # that one sample moves entries of the two layers below it by percents.  Those two layers are compared by
     # direction and norm; every other gradient, and every gradient of the other fixtures, entry by entry.
     at_kink = ('density_net0.0.', 'density_net0.2.') if tag == 'small_noview' else ()
+    measured = {}
     for k, v in m.named_parameters():
         if k.endswith('scales'):
             continue
@@ -100,10 +104,13 @@ def test_nerf_end_to_end_golden(golden, tag):
             a, b = v.grad.cpu().reshape(-1).double(), T(fx['grad_' + k]).reshape(-1).double()
             assert float(a @ b / (a.norm() * b.norm())) > 0.995 and abs(float(a.norm() / b.norm()) - 1) < 0.05, k
         elif 'grad_' + k in fx:
-            assert relerr(v.grad.cpu(), T(fx['grad_' + k])) < 1e-3, k
+            measured[k] = relerr(v.grad.cpu(), T(fx['grad_' + k]))
+            assert measured[k] < GRAD_GATE_FP32, (k, measured[k])
         else:
             assert abs(float(v.grad.norm()) - float(fx['gnorm_' + k])) < 1e-3 * float(fx['gnorm_' + k]) + 1e-9, k
-            assert relerr(v.grad.cpu().reshape(-1)[::97][:256], T(fx['gslice_' + k])) < 5e-3, k
+            measured[k] = relerr(v.grad.cpu().reshape(-1)[::97][:256], T(fx['gslice_' + k]))
+            assert measured[k] < 5e-3, (k, measured[k])
+    print(tag, 'fp32 path, worst gradient error relative to the tensor max: %.2e' % max(measured.values()))
 
 
 def test_state_dict_keys_match_reference_layout():

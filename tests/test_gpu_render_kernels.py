@@ -255,10 +255,12 @@ def test_scatter_backward_vs_oracle(ops, golden, wavelength):
     a = [x.clone().requires_grad_(True) for x in (raw_rgb, T(fx['angle']), raw_den)]
     rgb_a, den_a = O.activate(a[2], a[0], -1.0, 1e-4)
     ref = O.scatter(rgb_a, a[1], den_a, *args, wavelength)
-    (ref[0] * gp).sum().backward()
+    # the loss also reads the returned distance and acc (utils.py:380 returns both with their graph)
+    gd, ga = torch.randn(ref[1].shape, generator=g), torch.randn(ref[2].shape, generator=g)
+    ((ref[0] * gp).sum() + (ref[1] * gd).sum() + (ref[2] * ga).sum()).backward()
     b = [x.clone().cuda().requires_grad_(True) for x in (raw_rgb, T(fx['angle']), raw_den[..., 0])]
     got = ops.scatter(b[0], b[1], b[2], *[x.cuda() for x in args], wavelength, act=(True, 1e-4, -1.0))
-    (got[0] * gp.cuda()).sum().backward()
+    ((got[0] * gp.cuda()).sum() + (got[1] * gd.cuda()).sum() + (got[2] * ga.cuda()).sum()).backward()
     assert torch.equal(got[5].cpu().long(), ref[5])
     assert relerr(got[0].cpu(), ref[0]) < 1e-4
     assert relerr(b[0].grad.cpu(), a[0].grad) < 5e-4
@@ -430,3 +432,30 @@ def test_c_abi_rejects_bad_arguments():
     assert float(buf.abs().sum()) == 0.0                                        # nothing was written
     for code in (-1, -2, -3, -4):
         assert len(L.nerf_error_string(code)) > 0
+
+
+def test_integration_snippet_runs(ops):
+    """The hand-written ctypes binding quoted in INTEGRATION.md (examples/composite_ctypes.py) calls
+    nerf_composite_fwd with the prototype's 14 arguments and returns what `ops.composite` returns; the document
+    quotes the file verbatim."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, 'examples', 'composite_ctypes.py')
+    text = open(path).read()
+    body = text[text.index('# --- begin snippet\n') + len('# --- begin snippet\n'):text.index('# --- end snippet')]
+    assert body in open(os.path.join(root, 'INTEGRATION.md')).read()
+    spec = importlib.util.spec_from_file_location('composite_ctypes', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = torch.Generator().manual_seed(12)
+    n, S = 33, 40
+    rgb = torch.rand(n, S, 3, generator=g).cuda()
+    den = torch.randn(n, S, generator=g).cuda()
+    t = torch.sort(torch.rand(n, S + 1, generator=g) * 4 + 2, dim=-1)[0].cuda()
+    dirs = torch.randn(n, 3, generator=g).cuda()
+    for wb in (False, True):
+        got = mod.volumetric_rendering_fwd(rgb, den, t, dirs, wb, 0.001, -1.0)
+        want = ops.composite(rgb, den, t, dirs, wb, act=(True, 0.001, -1.0))
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)

@@ -37,7 +37,7 @@ def _shard_loss(p, rays, tgt, cfg, lo, hi, mask_sum):
 
 
 def _worker(rank, world, port, n, q):
-    from nerf_amd.train import allreduce_grads, shard_range
+    from nerf_amd.train import GradBucket, _all_reduce_sum, shard_range
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(1)
@@ -46,9 +46,16 @@ def _worker(rank, world, port, n, q):
     params = [torch.nn.Parameter(v) for v in O.init_params(cfg, seed=3).values()]
     p = dict(zip(O.init_params(cfg, seed=3).keys(), params))
     lo, hi = shard_range(n, rank, world)
-    mask_sum = rays.lossmult.sum()                                      # global, identical on every rank
+    # the step's own recipe: gradients are views of one flat bucket; the loss denominator is the mask sum of the
+    # whole batch, obtained by adding up the (unequal) shards' sums
+    bucket = GradBucket(params)
+    bucket.zero()
+    mask_sum = rays.lossmult[lo:hi].sum().clone()
+    _all_reduce_sum(mask_sum)
     _shard_loss(p, rays, tgt, cfg, lo, hi, mask_sum).backward()
-    allreduce_grads(params, world)
+    bucket.attach()
+    assert all(x.grad.data_ptr() == v.data_ptr() for x, v in zip(params, bucket.views))
+    bucket.all_reduce(world)
     q.put((rank, lo, hi, [x.grad.numpy().copy() for x in params]))     # by value: the worker may exit first
     dist.barrier()
     dist.destroy_process_group()
