@@ -233,7 +233,7 @@ def test_sar_forward_raises_beyond_the_last_range_bin():
     from nerf_amd.model import SARNeRF
     R = 256
     b = _sar_pulse(R, nsam=64, nfft=128, seed=3)
-    b['far'] = b['near'] + 400.0                   # bins end at near + 31.5 m
+    b['far'], b['mpp'] = b['near'] + 400.0, torch.tensor([0.01])     # the 64 bins end 0.63 m behind the near plane
     b['t_rand'], b['u_rand'] = None, None
     cfg = _sar_cfg('bf16', 0.03, R)
     cfg.randomized = False

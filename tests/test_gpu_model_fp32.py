@@ -72,7 +72,12 @@ def _rays(fx):
     return Rays(*(G(fx['ray_' + k]) for k in ('origins', 'directions', 'viewdirs', 'radii', 'lossmult', 'near', 'far')))
 
 
-GRAD_GATE_FP32 = 1e-3        # of the tensor's largest entry
+# Parameter gradients of the exact-fp32 path against the reference's autograd, as error over the tensor's largest
+# entry.  Full tensors (64-wide nets): gate 1e-4, measured <= 1e-6.  8x256 nets (a 256-element strided slice per
+# tensor is stored): measured 1.6e-3 (c1) and 2.8e-3 (c3) -- with 25 million ReLU decisions per batch a few sit
+# within fp32 rounding of the kink and take the other side than on the CPU, and one such sample moves an entry of
+# a 64-ray gradient by that much -- gate 5e-3 there.
+GRAD_GATE_FP32 = 1e-4
 
 
 @pytest.mark.parametrize('tag', ['small', 'small_det', 'small_noview', 'c1', 'c3'])
