@@ -147,6 +147,18 @@ int nerf_scatter_fwd(const float* rgb, const float* angle, const float* density,
                      float* ray_ret, int32_t* ray_bin, float* comp, int32_t* winner, int32_t* status,
                      void* stream);
 
+/* nerf_scatter_fwd without caller-supplied work buffers and without any allocation: the winner and per-ray
+ * return buffers live in a device array inside the library (768 KiB per GPU, held until the process ends).  It has
+ * no counterpart in the reference; it is for callers that cannot allocate: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  Limits: n_rays <= 65536 and nsam <= 65536, else NERF_ERR_SIZE.
+ * Same outputs as nerf_scatter_fwd (ray_bin and comp remain caller buffers: the backward pass reads them).  Every
+ * call on a GPU uses that GPU's one array: calls that overlap on one GPU (two streams, two threads) race. */
+int nerf_scatter_fwd_static(const float* rgb, const float* angle, const float* density, const float* power,
+                            const float* t_vals, const float* dirs, const float* pulse_bins, int64_t n_rays,
+                            int num_samples, int nsam, float wavelength, const nerf_activation* act,
+                            float* pulse, float* distance, float* acc, float* weights, float* alpha,
+                            int32_t* ray_bin, float* comp, int32_t* status, void* stream);
+
 /* Gradient of nerf_scatter_fwd w.r.t. rgb, angle, density given g_pulse[nsam,2]; every ray of
  * a bin receives the bin's gradient (reference autograd behaviour for the indexed +=).
  * g_distance[R] / g_acc[R] (nullable = zero) are the gradients w.r.t. the returned distance and acc

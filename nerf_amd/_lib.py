@@ -42,6 +42,8 @@ _SIGS = {
                                    _P, _P, _P]),
     'nerf_scatter_fwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_float,
                                  POINTER(NerfActivation), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'nerf_scatter_fwd_static': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_float,
+                                        POINTER(NerfActivation), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'nerf_scatter_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_float,
                                  POINTER(NerfActivation), _P, _P, _P, _P]),
     'nerf_gemm_f32': (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, c_int64, c_int64, c_int, c_int64,

@@ -4,6 +4,8 @@
 // is a wave-level scan (chunks of 64 samples, carried across chunks), reductions are wave
 // butterflies.  HBM-bound: every input element is read once in the forward pass and once in
 // the backward pass.
+#include <mutex>
+
 #include "common.h"
 
 struct ActParams {
@@ -462,6 +464,49 @@ extern "C" int nerf_scatter_fwd(const float* rgb, const float* angle, const floa
     hipLaunchKernelGGL(scatter_write_kernel, dim3(nerf_blocks(nsam, 256)), dim3(256), 0, st, ray_ret, winner, nsam,
                        pulse);
     return nerf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// nerf_scatter_fwd for callers that cannot allocate (HIP graph capture, serving loops): the two work buffers of
+// the scatter -- the per-bin winner indices and the per-ray complex returns -- live in a file-scope device array
+// instead of coming from the caller.  Each GPU holds its own copy of the array at its own address; that address
+// is looked up once per device, on the first call made with that device current, and only it (never the array's
+// name, which in host code is a stand-in and not a device address) is handed to memsets and kernels.
+constexpr int kStaticMaxBins = 65536;       // nsam     <= 65536: 256 KiB of winners
+constexpr int kStaticMaxRays = 65536;       // n_rays   <= 65536: 512 KiB of returns
+static __device__ __align__(256) unsigned char scratch[(size_t)kStaticMaxBins * 4 + (size_t)kStaticMaxRays * 8];
+static void* g_scratch_ptr[64] = {};        // per device
+static std::mutex g_scratch_mutex;
+
+static int static_scratch(unsigned char** out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return NERF_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || p == nullptr) return NERF_ERR_LAUNCH;
+        g_scratch_ptr[dev] = p;
+    }
+    *out = (unsigned char*)g_scratch_ptr[dev];
+    return NERF_OK;
+}
+
+extern "C" int nerf_scatter_fwd_static(const float* rgb, const float* angle, const float* density, const float* power,
+                                       const float* t_vals, const float* dirs, const float* pulse_bins,
+                                       int64_t n_rays, int num_samples, int nsam, float wavelength,
+                                       const nerf_activation* act, float* pulse, float* distance, float* acc,
+                                       float* weights, float* alpha, int32_t* ray_bin, float* comp, int32_t* status,
+                                       void* stream) {
+    NERF_REQUIRE(n_rays >= 0 && nsam >= 1);
+    if (n_rays > kStaticMaxRays || nsam > kStaticMaxBins) return NERF_ERR_SIZE;
+    unsigned char* base = nullptr;
+    const int rc = static_scratch(&base);
+    if (rc != NERF_OK) return rc;
+    int32_t* winner = (int32_t*)base;                                           // [nsam], cleared by every call
+    float* ray_ret = (float*)(base + (size_t)kStaticMaxBins * 4);               // [n_rays, 2], written before read
+    return nerf_scatter_fwd(rgb, angle, density, power, t_vals, dirs, pulse_bins, n_rays, num_samples, nsam,
+                            wavelength, act, pulse, distance, acc, weights, alpha, ray_ret, ray_bin, comp, winner,
+                            status, stream);
 }
 
 extern "C" int nerf_scatter_bwd(const float* rgb, const float* angle, const float* density, const float* power,
