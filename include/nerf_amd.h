@@ -216,10 +216,14 @@ typedef struct nerf_mlp_dims {
 int nerf_mlp_sizes(const nerf_mlp_dims* dims, int64_t* wfwd_bytes, int64_t* wbwd_bytes,
                    int64_t* consts_floats);
 
-/* Repack the fp32 [out,in] weights of the 10 streamed layers (density_net0.{0,2,4,6},
- * density_net1.{0,2,4,6}, rgb_net0.0, rgb_net1.0, in that order) into MFMA A-operand fragment
- * order: wfwd for the forward chain, wbwd (nullable) transposed for the backward chain.  Call
- * after every optimizer step.                     reference: the nn.Linear weights of model.py:54-93 */
+/* Repack fp32 [out,in] weights into MFMA A-operand fragment order: wfwd for the forward chain, wbwd (nullable)
+ * transposed for the backward chain.  weights[11]: [0..3] density_net0.{0,2,4,6}, [4..7] density_net1.{0,2,4,6},
+ * [8] the folded colour layer [width, hidden + view_dim] = [rgb_net1.0[:, :hidden] * rgb_net0.0 | rgb_net1.0[:, hidden:]]
+ * (rgb_net0 has no activation upstream, model.py:82-84, so the two layers are one affine map of [trunk | view]; the
+ * caller forms the fp32 product, and the folded bias rgb_net1.0[:, :hidden] * b_rgb_net0 + b_rgb_net1 goes into the
+ * constants block), [9] the density head row [1, hidden] (SAR: final_density.1 weight * LayerNorm gamma), [10] the
+ * colour heads [3, width] (SAR: final_rgb and final_angle stacked, [5, width]).  Call after every optimizer step.
+ *                                                  reference: the nn.Linear weights of model.py:54-93 */
 int nerf_mlp_pack(const nerf_mlp_dims* dims, const float* const* weights, void* wfwd, void* wbwd,
                   void* stream);
 
@@ -238,8 +242,9 @@ int nerf_view_frag(const float* dirs, int64_t n_rays, int min_deg, int max_deg, 
  * raw_angle[M,2] (SAR).  Row m takes the view features of ray m / ray_div (NeRF, ray_div = samples
  * per ray) or m % ray_div (SAR, ray_div = rays per chunk -- the row order upstream produces,
  * model.py:351-354).  acts: NULL for inference, else 22 (SAR: 23) device pointers that receive what the
- * backward pass reads: [0..9] the activations X0..X9 as transposed bf16 fragments (nblk * features
- * * 128 bytes each, nblk = 4 * ceil(M / 256)), [10..19] their ReLU sign words (nblk * 2 *
+ * backward pass reads: [0..7], [9] the outputs X0..X7 of the trunk layers and X9 of the colour layer as transposed
+ * bf16 fragments (nblk * features * 128 bytes each, nblk = 4 * ceil(M / 256); [8] unused, may be NULL: rgb_net0's
+ * output is never formed), [10..19] their ReLU sign words (nblk * 2 *
  * ceil(features / 64) * 256 bytes; [18] unused, may be NULL), [20] / [21] the position encoding and
  * view features as transposed fragments, [22] (SAR only) the trunk output in fragment order (nblk * H_padded
  * * 128 bytes).                                        reference: model.py:117-132, 343-359 */
@@ -250,8 +255,8 @@ int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* const
 /* Backward chain of the fused MLP: from dL/d raw_density [M], dL/d raw_rgb [M,3] (w.r.t. the
  * post-sigmoid output; raw_rgb is that saved output) through every layer, writing dL/d(layer
  * pre-activation) as transposed bf16 fragments (feature on the lane, 16 samples per k-step:
- * [block of 32 samples][2][features/32][64 lanes][8]): dys[0..9] for the ten streamed layers,
- * dys[10] / dys[11] the 32-row head tiles (colour heads / density head).  acts are the 22 buffers
+ * [block of 32 samples][2][features/32][64 lanes][8]): dys[0..7] for the trunk layers, dys[9] for the colour layer
+ * (dys[8] unused, may be NULL), dys[10] / dys[11] the 32-row head tiles (colour heads / density head).  acts are the 22 buffers
  * nerf_mlp_fwd saved (only the ReLU sign words acts[10..19] are read; SAR also acts[22]).  SAR heads
  * (model.py:278-302): g_angle [M,2], raw_angle, raw_density (the forward's outputs), ln_stats and the forward
  * constants block are required too; the density head tile then carries rows g*rstd, g*rstd*mean, g, from which

@@ -24,6 +24,13 @@
 // The weight-gradient kernel then streams T-frags HBM -> LDS -> MFMA operands with no transposition at all.
 // ReLU decisions travel to the backward chain as one bit per unit (a 32-bit word per lane per two tiles).
 //
+// Folded colour layer.  The reference's rgb_net0 has no activation (model.py:82-84), so rgb_net1's pre-activation
+// W9 [W8 x7 + b8 | view] + b9 is one affine map of [x7 | view]: the chain multiplies by the folded matrix
+// [W9a W8 | W9v] (fp32 product of the masters, rounded to bf16 once) and never forms rgb_net0's output.  Forward,
+// input-gradient chain and weight-gradient pass each drop a 256 x 256 product and the saved copies that went
+// with it; the gradients of the two original matrices follow from G = dY9^T X7 by two small fp32 products
+// (dW8 = W9a^T G, dW9a = G W8^T + db9 b8^T) on the host side of the ABI.
+//
 // Kernels: weight packing (forward and transposed streams), fused cast+IPE encoder and view-feature
 // encoder emitting frags, the forward chain, the backward chain (dX through all layers, emitting dY
 // T-frags) and the streaming weight-gradient GEMM.  bf16 inputs, fp32 accumulation and epilogues.
@@ -138,22 +145,22 @@ struct Net {
     static constexpr int HKS = 2 * HT, WKS = 2 * WT, HP = 32 * HT, WP = 32 * WT;
     static constexpr int NHEAD = SAR ? 5 : 3;            // rgb (3) [+ angle (2)]
     // fp32 constants block (floats): biases, laid out per 32-row tile like the accumulators read them
-    static constexpr int C_BIAS = 0;                     // layers 0..8: 9 x HP
-    static constexpr int C_BIAS9 = 9 * HP;               // colour layer: WP
+    static constexpr int C_BIAS = 0;                     // trunk layers 0..7: 8 x HP
+    static constexpr int C_BIAS9 = 8 * HP;               // folded colour layer: WP
     static constexpr int C_BIASD = C_BIAS9 + WP;         // density head tile: 32 (row 0 = bias)
     static constexpr int C_BIASH = C_BIASD + 32;         // rgb/angle head tile: 32 (rows 0..4 = biases)
     static constexpr int C_SC = C_BIASH + 32;            // scalars: [6] sum(w*gamma) [7] sum(w*beta) [8] 1/H [9] eps
     static constexpr int C_TOTAL = C_SC + 16;
     static constexpr int SLOT_KS = HKS + (DKS > VKS ? DKS : VKS);
     static constexpr int FWD_LDS = C_TOTAL * 4 + (kRing * kTPS * SLOT_KS + 1) * 1024;   // + 1 KiB landing zone
-    static constexpr int BWD_SLOT_KS = (HKS + 1) > WKS ? (HKS + 1) : WKS;
+    static constexpr int BWD_SLOT_KS = HKS > (WKS + 1) ? HKS : (WKS + 1);
     static constexpr int BWD_LDS = (kRing * kTPS * BWD_SLOT_KS + 1) * 1024;
     // pieces (1 KiB) in the packed streams
-    // forward: L0, L1-3, L4, L5-7, density head tile, L8, L9, rgb/angle head tile
-    static constexpr int FWD_PIECES = HT * DKS + 3 * HT * HKS + HT * (HKS + DKS) + 3 * HT * HKS + HKS + HT * HKS +
+    // forward: L0, L1-3, L4, L5-7, density head tile, folded colour layer, rgb/angle head tile
+    static constexpr int FWD_PIECES = HT * DKS + 3 * HT * HKS + HT * (HKS + DKS) + 3 * HT * HKS + HKS +
                                       WT * (HKS + VKS) + WKS;
-    // backward: heads^T (1 k-step), L9^T, L8^T (+1 k-step: density head row), L7..L5^T, L4^T, L3..L1^T
-    static constexpr int BWD_PIECES = WT * 1 + HT * WKS + HT * (HKS + 1) + 7 * HT * HKS;
+    // backward: heads^T (1 k-step), folded colour layer^T (+1 k-step: density head row), L7..L5^T, L4^T, L3..L1^T
+    static constexpr int BWD_PIECES = WT * 1 + HT * (WKS + 1) + 7 * HT * HKS;
 };
 
 struct MlpFwdArgs {
@@ -165,7 +172,7 @@ struct MlpFwdArgs {
     int64_t nblk;              // blocks of 64 samples
     int ray_div;               // NeRF: samples per ray S (ray = m / S);  SAR: rays per chunk R (ray = m % R)
     int n_rays;
-    bf16x8* tx[10];            // saved activations X0..X9 as T-frags (training only)
+    bf16x8* tx[10];            // saved activations X0..X7, X9 as T-frags (training only; index 8 unused)
     unsigned* mask[10];        // ReLU sign words of X0..X7, X9: [b32][ceil(tiles/2)][64] (index 8 unused)
     bf16x8* t_enc;             // position encoding as T-frags, ceil(DKS/2) tiles
     bf16x8* t_view;            // view features as T-frags, ceil(VKS/2) tiles
@@ -195,15 +202,15 @@ constexpr int kLdsAhead = NERF_LDS_AHEAD;     // weight pieces in flight LDS -> 
 // tile's MFMAs) | stores.
 struct StageDesc { int ks, pre, xloads, stores; };      // ks = pieces of the whole stage
 
-// Forward layers: L0, L1-3, L4, L5-7 (HT tiles each), density head (1), L8 (HT), L9 (WT), colour heads (1).
+// Forward layers: L0, L1-3, L4, L5-7 (HT tiles each), density head (1), folded colour layer (WT), colour heads (1).
 template <class N, bool SAVE>
 constexpr StageDesc fwd_stage(int i) {
-    constexpr int kL = 12;
-    const int tiles[kL] = {N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, 1, N::HT, N::WT, 1};
-    const int ks[kL] = {N::DKS, N::HKS, N::HKS, N::HKS, N::HKS + N::DKS, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS,
+    constexpr int kL = 11;
+    const int tiles[kL] = {N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, 1, N::WT, 1};
+    const int ks[kL] = {N::DKS, N::HKS, N::HKS, N::HKS, N::HKS + N::DKS, N::HKS, N::HKS, N::HKS, N::HKS,
                         N::HKS + N::VKS, N::WKS};
-    // 0 head (nothing saved), 1 saved, 2 saved + sign words, 3 as 2 + a frag-order copy (SAR trunk output)
-    const int kind[kL] = {2, 2, 2, 2, 2, 2, 2, N::SAR ? 3 : 2, 0, 1, 2, 0};
+    // 0 head (nothing saved), 2 saved + sign words, 3 as 2 + a frag-order copy (SAR trunk output)
+    const int kind[kL] = {2, 2, 2, 2, 2, 2, 2, N::SAR ? 3 : 2, 0, 2, 0};
     // stores that finishing tile t of layer l issues: 2 T-frag pieces, + the sign word after every second tile
     auto tile_stores = [&](int l, int t) {
         return (!SAVE || kind[l] == 0) ? 0 : 2 + ((kind[l] >= 2 && ((t & 1) || t + 1 == tiles[l])) ? 1 : 0) + (kind[l] == 3 ? 2 : 0);
@@ -220,14 +227,14 @@ constexpr StageDesc fwd_stage(int i) {
     }
     return {0, 0, 0, 0};
 }
-// Backward layers: heads^T (WT tiles, 1 k-step), L9^T (HT, WKS), L8^T + density row (HT, HKS+1), 7 x (HT, HKS).
+// Backward layers: heads^T (WT tiles, 1 k-step), folded colour layer^T + density row (HT, WKS+1), 7 x (HT, HKS).
 // Finishing a tile stores 2 T-frag pieces; the first stage of a layer also loads the next masked layer's sign words.
 template <class N>
 constexpr StageDesc bwd_stage(int i) {
-    constexpr int kL = 10;
-    const int tiles[kL] = {N::WT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT};
-    const int ks[kL] = {1, N::WKS, N::HKS + 1, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS};
-    const bool masked[kL + 1] = {true, false, true, true, true, true, true, true, true, true, false};
+    constexpr int kL = 9;
+    const int tiles[kL] = {N::WT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT};
+    const int ks[kL] = {1, N::WKS + 1, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS};
+    const bool masked[kL + 1] = {true, true, true, true, true, true, true, true, true, false};
     if (i < 0) return {0, 0, 0, 0};
     for (int l = 0; l < kL; ++l) {
         if (i < stage_count(tiles[l])) {
@@ -529,13 +536,12 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     fwd_layer<N, SAVE, 5 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 5 * N::HP, h, a.tx[5], a.mask[5], b32, P, hd_density, ln);
     fwd_layer<N, SAVE, 6 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 6 * N::HP, h, a.tx[6], a.mask[6], b32, P, hd_density, ln);
     fwd_layer<N, SAVE, 7 * HS, HT, HKS, 0, true, EPI_TRUNK>(pipe, xa, none, xb, bias + 7 * N::HP, h, a.tx[7], a.mask[7], b32, P, hd_density, ln, a.x7_frag);
-    // final_density as one more output tile on X7 (row 0), then rgb_net0 (no activation): X7 -> X8
+    // final_density as one more output tile on X7 (row 0)
     fwd_layer<N, SAVE, 8 * HS, 1, HKS, 0, false, EPI_HEAD>(pipe, xb, none, xw, cst + N::C_BIASD, h, nullptr, nullptr, b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, 8 * HS + 1, HT, HKS, 0, false, EPI_PLAIN>(pipe, xb, none, xa, bias + 8 * N::HP, h, a.tx[8], nullptr, b32, P, hd_colour, ln);
-    // rgb_net1: [X8 | view] -> X9 ; final_rgb (+ final_angle) as one output tile on X9 (rows 0..4)
-    fwd_layer<N, SAVE, 9 * HS + 1, N::WT, HKS, N::VKS, true, EPI_PLAIN>(pipe, xa, view, xw, cst + N::C_BIAS9, h, a.tx[9], a.mask[9], b32, P, hd_colour, ln);
-    fwd_layer<N, SAVE, 9 * HS + 1 + WS, 1, N::WKS, 0, false, EPI_HEAD>(pipe, xw, none, xa, cst + N::C_BIASH, h, nullptr, nullptr, b32, P, hd_colour, ln);
-    static_assert(fwd_stage<N, SAVE>(9 * HS + 2 + WS).ks == 0 && fwd_stage<N, SAVE>(9 * HS + 1 + WS).ks == N::WKS, "stage table out of step");
+    // rgb_net0 folded into rgb_net1: [X7 | view] -> X9 ; final_rgb (+ final_angle) as one output tile on X9 (rows 0..4)
+    fwd_layer<N, SAVE, 8 * HS + 1, N::WT, HKS, N::VKS, true, EPI_PLAIN>(pipe, xb, view, xw, cst + N::C_BIAS9, h, a.tx[9], a.mask[9], b32, P, hd_colour, ln);
+    fwd_layer<N, SAVE, 8 * HS + 1 + WS, 1, N::WKS, 0, false, EPI_HEAD>(pipe, xw, none, xa, cst + N::C_BIASH, h, nullptr, nullptr, b32, P, hd_colour, ln);
+    static_assert(fwd_stage<N, SAVE>(8 * HS + 2 + WS).ks == 0 && fwd_stage<N, SAVE>(8 * HS + 1 + WS).ks == N::WKS, "stage table out of step");
 
     // outputs.  Lane half 0 holds rows 0..3 of a head tile, half 1 rows 4..7.
     const float* sc = cst + N::C_SC;
@@ -584,8 +590,8 @@ struct MlpBwdArgs {
     const float* raw_density;  // [M]   (SAR: the forward's density output)
     const float* consts;       // the forward constants block (SAR: LayerNorm scalars)
     const bf16x8* x7_frag;     // SAR: trunk output in frag order
-    const unsigned* mask[10];  // ReLU sign words of X0..X9 (index 8 unused)
-    bf16x8* tdy[10];           // dY0..dY9 as T-frags
+    const unsigned* mask[10];  // ReLU sign words of X0..X7, X9 (index 8 unused)
+    bf16x8* tdy[10];           // dY0..dY7, dY9 as T-frags (index 8 unused)
     bf16x8* tdy_hd;            // 1-tile T-frag of dL/d(pre-sigmoid colour outputs), rows 0..4
     bf16x8* tdy_dens;          // 1-tile T-frag of dL/d raw_density (row 0); SAR rows 0..2: g*rstd, g*rstd*mean, g
 };
@@ -733,20 +739,18 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
 
     bf16x8 ga[HKS], gb[HKS], gw[WKS], none[1], dzv[1] = {dz}, ddv[1] = {dd};
     // heads^T: dX9 = Wh^T dz, masked by X9 > 0 -> dY9
-    bwd_layer<N, 0, WT, 1, 0, true, 0>(pipe, dzv, none, gw, kw9, nullptr, nokw, a.tdy[9], b32, P);
-    // rgb_net1^T (rows of X8 only): dY8 = W9[:, :H]^T dY9   (rgb_net0 has no activation)
-    bwd_layer<N, WS, HT, WKS, 0, false, HW>(pipe, gw, none, ga, nokw, a.mask[7], kwa, a.tdy[8], b32, P);
-    // [rgb_net0 ; density head]^T: dX7 = W8^T dY8 + wd^T dd, masked by X7 > 0 -> dY7
-    bwd_layer<N, WS + 1 * HS, HT, HKS, 1, true, HW, N::SAR>(pipe, ga, ddv, gb, kwa, a.mask[6], kwb, a.tdy[7], b32, P, x7, c0, c1);
-    bwd_layer<N, WS + 2 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[5], kwa, a.tdy[6], b32, P);
-    bwd_layer<N, WS + 3 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[4], kwb, a.tdy[5], b32, P);
-    bwd_layer<N, WS + 4 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[3], kwa, a.tdy[4], b32, P);
+    bwd_layer<N, 0, WT, 1, 0, true, HW>(pipe, dzv, none, gw, kw9, a.mask[7], kwa, a.tdy[9], b32, P);
+    // [folded colour layer (columns of X7 only) ; density head]^T: dX7 = (W9a W8)^T dY9 + wd^T dd, masked by X7 > 0 -> dY7
+    bwd_layer<N, WS, HT, WKS, 1, true, HW, N::SAR>(pipe, gw, ddv, gb, kwa, a.mask[6], kwb, a.tdy[7], b32, P, x7, c0, c1);
+    bwd_layer<N, WS + 1 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[5], kwa, a.tdy[6], b32, P);
+    bwd_layer<N, WS + 2 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[4], kwb, a.tdy[5], b32, P);
+    bwd_layer<N, WS + 3 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[3], kwa, a.tdy[4], b32, P);
     // density_net1.0^T (rows of X3 only; the encoding needs no gradient)
-    bwd_layer<N, WS + 5 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[2], kwb, a.tdy[3], b32, P);
-    bwd_layer<N, WS + 6 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[1], kwa, a.tdy[2], b32, P);
-    bwd_layer<N, WS + 7 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[0], kwb, a.tdy[1], b32, P);
-    bwd_layer<N, WS + 8 * HS, HT, HKS, 0, true, 0>(pipe, gb, none, ga, kwb, nullptr, nokw, a.tdy[0], b32, P);
-    static_assert(bwd_stage<N>(WS + 9 * HS).ks == 0 && bwd_stage<N>(WS + 9 * HS - 1).ks != 0, "stage table out of step");
+    bwd_layer<N, WS + 4 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[2], kwb, a.tdy[3], b32, P);
+    bwd_layer<N, WS + 5 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[1], kwa, a.tdy[2], b32, P);
+    bwd_layer<N, WS + 6 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[0], kwb, a.tdy[1], b32, P);
+    bwd_layer<N, WS + 7 * HS, HT, HKS, 0, true, 0>(pipe, gb, none, ga, kwb, nullptr, nokw, a.tdy[0], b32, P);
+    static_assert(bwd_stage<N>(WS + 8 * HS).ks == 0 && bwd_stage<N>(WS + 8 * HS - 1).ks != 0, "stage table out of step");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1314,9 +1318,9 @@ extern "C" int nerf_mlp_sizes(const nerf_mlp_dims* dims, int64_t* wfwd_bytes, in
     return NERF_ERR_SIZE;
 }
 
-// weights[12], all fp32 [out,in]: 0-3 density_net0.{0,2,4,6}, 4-7 density_net1.{0,2,4,6}, 8 rgb_net0.0,
-// 9 rgb_net1.0, 10 the density head row [1,H] (SAR: final_density weight * LayerNorm gamma),
-// 11 the colour heads [3,W] (SAR: final_rgb and final_angle stacked, [5,W]).
+// weights[11], all fp32 [out,in]: 0-3 density_net0.{0,2,4,6}, 4-7 density_net1.{0,2,4,6}, 8 the folded colour layer
+// [W, H+V] = [rgb_net1.0[:, :H] rgb_net0.0 | rgb_net1.0[:, H:]], 9 the density head row [1,H] (SAR: final_density
+// weight * LayerNorm gamma), 10 the colour heads [3,W] (SAR: final_rgb and final_angle stacked, [5,W]).
 extern "C" int nerf_mlp_pack(const nerf_mlp_dims* dims, const float* const* weights, void* wfwd, void* wbwd,
                              void* stream) {
     HostDims d;
@@ -1345,20 +1349,19 @@ extern "C" int nerf_mlp_pack(const nerf_mlp_dims* dims, const float* const* weig
                            n2_true, k_true, KT, NS, NS2, b);
         b += total;
     };
-    for (int i = 0; i < 12; ++i) NERF_REQUIRE(weights[i] != nullptr);
+    for (int i = 0; i < 11; ++i) NERF_REQUIRE(weights[i] != nullptr);
     pf(weights[0], d.D, d.H, 0, 0, d.D, d.DKS, d.HT);
     for (int i = 1; i < 4; ++i) pf(weights[i], d.H, d.H, d.H, HKS, 0, 0, d.HT);
     pf(weights[4], d.H + d.D, d.H, d.H, HKS, d.D, d.DKS, d.HT);
     for (int i = 5; i < 8; ++i) pf(weights[i], d.H, d.H, d.H, HKS, 0, 0, d.HT);
-    pf(weights[10], d.H, 1, d.H, HKS, 0, 0, 1);                     // density head: one tile, row 0
-    pf(weights[8], d.H, d.H, d.H, HKS, 0, 0, d.HT);
-    pf(weights[9], d.H + d.V, d.W, d.H, HKS, d.V, d.VKS, d.WT);
-    pf(weights[11], d.W, d.sar ? 5 : 3, d.W, 2 * d.WT, 0, 0, 1);    // rgb (+angle) heads: one tile, rows 0..4
+    pf(weights[9], d.H, 1, d.H, HKS, 0, 0, 1);                      // density head: one tile, row 0
+    pf(weights[8], d.H + d.V, d.W, d.H, HKS, d.V, d.VKS, d.WT);     // folded colour layer
+    pf(weights[10], d.W, d.sar ? 5 : 3, d.W, 2 * d.WT, 0, 0, 1);    // rgb (+angle) heads: one tile, rows 0..4
     if (wbwd != nullptr) {
-        // consumption order of the backward chain: layer 9, 8, 7, ..., 1 (layer 0 needs no input gradient)
-        pb(weights[11], d.W, d.sar ? 5 : 3, d.W, d.WT, 1);               // heads^T: dX9 = Wh^T dZ, one k-step
-        pb(weights[9], d.H + d.V, d.W, d.H, d.HT, 2 * d.WT);
-        pb2(weights[8], d.H, d.H, weights[10], d.H, 1, d.H, d.HT, HKS, 1);  // [rgb_net0 ; density head]^T
+        // consumption order of the backward chain: heads, colour layer, 7, ..., 1 (layer 0 needs no input gradient)
+        pb(weights[10], d.W, d.sar ? 5 : 3, d.W, d.WT, 1);               // heads^T: dX9 = Wh^T dZ, one k-step
+        // [folded colour layer (its X7 columns) ; density head]^T
+        pb2(weights[8], d.H + d.V, d.W, weights[9], d.H, 1, d.H, d.HT, 2 * d.WT, 1);
         for (int i = 7; i >= 5; --i) pb(weights[i], d.H, d.H, d.H, d.HT, HKS);
         pb(weights[4], d.H + d.D, d.H, d.H, d.HT, HKS);
         for (int i = 3; i >= 1; --i) pb(weights[i], d.H, d.H, d.H, d.HT, HKS);
@@ -1415,7 +1418,7 @@ extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const f
     a.nblk = ((n_samples + 255) / 256) * 4;      // blocks of 64 samples, whole workgroups
     a.ray_div = ray_div;
     a.n_rays = (int)n_rays;
-    // acts (training): 0..9 T-frags of X0..X9, 10..19 sign-word buffers, 20 enc T-frags, 21 view T-frags
+    // acts (training): 0..9 T-frags of X0..X7, X9 (8 unused), 10..19 sign-word buffers (18 unused), 20 enc, 21 view T-frags
     for (int i = 0; i < 10; ++i) {
         a.tx[i] = acts ? (bf16x8*)acts[i] : nullptr;
         a.mask[i] = acts ? (unsigned*)acts[10 + i] : nullptr;
@@ -1423,7 +1426,7 @@ extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const f
     a.t_enc = acts ? (bf16x8*)acts[20] : nullptr;
     a.t_view = acts ? (bf16x8*)acts[21] : nullptr;
     a.x7_frag = (acts && d.sar) ? (bf16x8*)acts[22] : nullptr;
-    if (acts) for (int i = 0; i < 22; ++i) NERF_REQUIRE(acts[i] != nullptr || i == 18);
+    if (acts) for (int i = 0; i < 22; ++i) NERF_REQUIRE(acts[i] != nullptr || i == 8 || i == 18);
     if (acts && d.sar) NERF_REQUIRE(acts[22] != nullptr);
     a.raw_density = raw_density;
     a.raw_rgb = raw_rgb;
@@ -1450,7 +1453,7 @@ extern "C" int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, const f
                             const float* g_density, const float* g_rgb, const float* g_angle, const float* raw_density,
                             const float* raw_rgb, const float* raw_angle, const float* ln_stats,
                             void* const* acts /* as nerf_mlp_fwd */,
-                            void* const* dys /* 12 T-frag buffers: dY0..dY9, colour head tile, density head tile */,
+                            void* const* dys /* 12 T-frag buffers: dY0..dY7, unused, dY9, colour head tile, density head tile */,
                             void* stream) {
     if (n_samples == 0) return NERF_OK;
     HostDims d;
@@ -1465,7 +1468,7 @@ extern "C" int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, const f
     a.raw_density = raw_density; a.consts = consts;
     a.x7_frag = d.sar ? (const bf16x8*)acts[22] : nullptr;
     for (int i = 0; i < 10; ++i) {
-        NERF_REQUIRE((acts[10 + i] || i == 8) && dys[i]);
+        NERF_REQUIRE((acts[10 + i] && dys[i]) || i == 8);
         a.mask[i] = (const unsigned*)acts[10 + i];
         a.tdy[i] = (bf16x8*)dys[i];
     }

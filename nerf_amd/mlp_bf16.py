@@ -10,6 +10,7 @@ import torch
 
 from . import _lib, profiling
 from ._lib import MlpDims, check, f32c, lib, ptr, stream
+from .mlp import gemm
 
 _P = c_void_p
 _lib.register('nerf_mlp_sizes', c_int, [POINTER(MlpDims), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)])
@@ -76,18 +77,24 @@ class Packed:
             self.head_density = wd.contiguous()
             self.head_colour = p['final_rgb.0.weight'].contiguous()
             head_bias = p['final_rgb.0.bias']
-        mats = [f32c(p[n + '.weight']) for n in STREAMED] + [f32c(self.head_density), f32c(self.head_colour)]
+        # rgb_net0 (no activation, model.py:82-84) folded into rgb_net1: one matrix on [trunk output | view features]
+        self.W8, self.b8 = f32c(p['rgb_net0.0.weight']), f32c(p['rgb_net0.0.bias'])
+        self.W9 = f32c(p['rgb_net1.0.weight'])
+        fold = self.W9.clone()
+        fold[:, :H] = gemm(self.W9, (H + V, 1), self.W8, (H, 1), W, H, H)                        # W9[:, :H] @ W8
+        bias9 = gemm(self.b8, (H, 1), self.W9, (1, H + V), 1, W, H, bias=f32c(p['rgb_net1.0.bias']))[0]  # b8 W9a^T + b9
+        mats = [f32c(p[n + '.weight']) for n in STREAMED[:8]] + [fold, f32c(self.head_density), f32c(self.head_colour)]
         self._keep = mats
-        arr = (c_void_p * 12)(*[m.data_ptr() for m in mats])
+        arr = (c_void_p * 11)(*[m.data_ptr() for m in mats])
         check(lib().nerf_mlp_pack(ctypes.byref(self.dims), arr, _raw(self.wfwd),
                                   _raw(self.wbwd) if need_bwd else None, stream()))
 
         # fp32 constants block (layout: Net::C_* in mlp_bf16.hip)
         c = torch.zeros(nc.value, dtype=torch.float32, device=dev)
-        for i, n in enumerate(STREAMED[:9]):
+        for i, n in enumerate(STREAMED[:8]):
             c[i * HP:i * HP + H] = p[n + '.bias']
-        o = 9 * HP
-        c[o:o + W] = p['rgb_net1.0.bias']
+        o = 8 * HP
+        c[o:o + W] = bias9
         o += WP
         if not self.sar:
             c[o] = bd[0]
@@ -128,14 +135,13 @@ def _wgrad_plan(pk):
     plan += [([(4, HP, H, 'density_net1.0')], [(('x', 3), HP, H), ('enc', DP, D)],
               [[('density_net1.0', 0), ('density_net1.0', H)]])]
     plan += [one(l, HP, H, 'density_net1.%d' % i, ('x', l - 1), HP, H) for l, i in ((5, 2), (6, 4), (7, 6))]
-    # rgb_net0 and the density head both read the trunk output X7
+    # the folded colour layer and the density head both read the trunk output X7: [dY9 | density tile] x [X7 | view]
+    # in one launch.  dY9^T X7 lands in the scratch pair '_g98' (fold_gradients turns it into the gradients of
+    # rgb_net0.0 and of the trunk columns of rgb_net1.0); dY9^T view is the gradient of rgb_net1.0's view columns.
     # (SAR: the density tile carries rows g*rstd, g*rstd*mean, g; they land in the scratch pair '_dens')
     dens = ('_dens', 3) if pk.sar else ('final_density.0', 1)
-    plan += [([(8, HP, H, 'rgb_net0.0'), (11, 32, dens[1], dens[0])], [(('x', 7), HP, H)],
-              [[('rgb_net0.0', 0)], [(dens[0], 0)]])]
-    # rgb_net1.0 takes [X8 | view features]
-    plan += [([(9, WP, W, 'rgb_net1.0')], [(('x', 8), HP, H), ('view', VP, V)],
-              [[('rgb_net1.0', 0), ('rgb_net1.0', H)]])]
+    plan += [([(9, WP, W, '_g98'), (11, 32, dens[1], dens[0])], [(('x', 7), HP, H), ('view', VP, V)],
+              [[('_g98', 0), ('rgb_net1.0', H)], [(dens[0], 0), None]])]
     # (SAR: rows 0..2 final_rgb, 3..4 final_angle, in the scratch pair '_heads')
     plan += [one(10, 32, 5, '_heads', ('x', 9), WP, W) if pk.sar else one(10, 32, 3, 'final_rgb.0', ('x', 9), WP, W)]
     return plan
@@ -193,9 +199,10 @@ def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False):
     ln_stats = torch.empty(n_samples, 2, device=dev) if (pk.sar and save) else None
     acts = arr = None
     if save:
-        # 0..9 X0..X9 as T-frags, 10..19 their ReLU sign words (X8 has no activation), 20 enc, 21 view T-frags
+        # 0..9 X0..X7, X9 as T-frags (8 unused: rgb_net0's output is never formed), 10..19 their ReLU sign words,
+        # 20 enc, 21 view T-frags
         tiles = [pk.HT] * 9 + [pk.WT]
-        acts = [torch.empty(nblk * t * 4096, dtype=torch.uint8, device=dev) for t in tiles]
+        acts = [torch.empty(nblk * t * 4096, dtype=torch.uint8, device=dev) if i != 8 else None for i, t in enumerate(tiles)]
         acts += [torch.empty(nblk * 2 * ((t + 1) // 2) * 256, dtype=torch.uint8, device=dev) if i != 8 else None
                  for i, t in enumerate(tiles)]
         acts += [torch.empty(nblk * pk.DT * 4096, dtype=torch.uint8, device=dev),
@@ -218,13 +225,13 @@ def mlp_backward(pk, acts, n_samples, g_density, g_rgb, raw_rgb, g_angle=None, r
     dev = g_density.device
     nblk = n_blocks(n_samples)
     tiles = [pk.HT] * 9 + [pk.WT, 1, 1]
-    dys = [torch.empty(nblk * t * 4096, dtype=torch.uint8, device=dev) for t in tiles]
+    dys = [torch.empty(nblk * t * 4096, dtype=torch.uint8, device=dev) if i != 8 else None for i, t in enumerate(tiles)]
     a_arr = (c_void_p * len(acts))(*[a.data_ptr() if a is not None else None for a in acts])
-    d_arr = (c_void_p * 12)(*[d.data_ptr() for d in dys])
+    d_arr = (c_void_p * 12)(*[d.data_ptr() if d is not None else None for d in dys])
     g_density, g_rgb = f32c(g_density).reshape(-1), f32c(g_rgb).reshape(-1, 3)
     if pk.sar:
         g_angle = f32c(g_angle).reshape(-1, 2)
-    with profiling.timed('mlp_bwd_kernel', flops=pk.bwd_dx_flops * n_samples, bytes_=float(sum(d.numel() for d in dys))):
+    with profiling.timed('mlp_bwd_kernel', flops=pk.bwd_dx_flops * n_samples, bytes_=float(sum(d.numel() for d in dys if d is not None))):
         check(lib().nerf_mlp_bwd(ctypes.byref(pk.dims), _raw(pk.wbwd), ptr(pk.consts), n_samples, ptr(g_density),
                                  ptr(g_rgb), ptr(g_angle), ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
                                  ptr(ln_stats), a_arr, d_arr, stream()))
@@ -254,8 +261,31 @@ def _wgrad(dy, n_feat, x, k_feat, n_samples, G, col0, n_true, k_true, gb):
                                    k_true, ptr(gb), 0, stream()))
 
 
+def fold_gradients(pk, grads):
+    """Gradients of rgb_net0.0 and of rgb_net1.0's trunk columns from what the folded layer's launch produced:
+    G = sum_m dY9 x7^T (grads['_g98.weight'], [W,H]) and s = sum_m dY9 (grads['_g98.bias']).  With
+    z9 = W9a (W8 x7 + b8) + W9v view + b9:   dW9a = G W8^T + s b8^T,  db9 = s,  dW8 = W9a^T G,  db8 = W9a^T s.
+    Small exact-fp32 products (split-K form: they add into the running gradients)."""
+    H, W, V = pk.H, pk.W, pk.V
+    G, s = grads['_g98.weight'], grads['_g98.bias']
+    g9, g8 = grads['rgb_net1.0.weight'], grads['rgb_net0.0.weight']
+    gemm(G, (H, 1), pk.W8, (1, H), W, H, H, split_k=2, out=g9)                        # += G W8^T   (columns 0..H-1)
+    gemm(s, (1, 1), pk.b8, (H, 1), W, H, 1, split_k=2, out=g9)                        # += s b8^T
+    gemm(pk.W9, (1, H + V), G, (H, 1), H, H, W, split_k=2, out=g8)                    # += W9a^T G
+    gemm(pk.W9, (1, H + V), s, (1, 1), H, 1, W, split_k=2, out=grads['rgb_net0.0.bias'].view(H, 1))   # += W9a^T s
+    grads['rgb_net1.0.bias'].add_(s)
+
+
 def mlp_weight_grads(pk, acts, dys, n_samples, grads):
     """Accumulate all weight / bias gradients into `grads` (name -> zero-initialised or running fp32 tensor)."""
+    dev = pk.consts.device
+    grads = dict(grads)
+    grads['_g98.weight'], grads['_g98.bias'] = torch.zeros(pk.W, pk.H, device=dev), torch.zeros(pk.W, device=dev)
+    _wgrad_launches(pk, acts, dys, n_samples, grads)
+    fold_gradients(pk, grads)
+
+
+def _wgrad_launches(pk, acts, dys, n_samples, grads):
     for dsegs, xsegs, blocks in _wgrad_plan(pk):
         d = WgradDesc()
         flops = 0.0
@@ -271,6 +301,8 @@ def mlp_weight_grads(pk, acts, dys, n_samples, grads):
                     w = grads[blk[0] + '.weight']
                     d.G[i][j], d.ld[i][j], d.col0[i][j] = w.data_ptr(), w.stride(0), blk[1]
                     flops += 2.0 * dsegs[i][2] * xsegs[j][2] * n_samples
+                    if blk[0] == '_g98':        # this block stands for rgb_net0's weight gradient as well
+                        flops += 2.0 * pk.H * pk.H * n_samples
         nf_all, kf_all = sum(s[1] for s in dsegs), sum(s[1] for s in xsegs)
         # algorithmic work of the launch: every operand byte once, 2 FLOP per true multiply-add
         with profiling.timed(wgrad_kernel_name(nf_all, kf_all), flops=flops, bytes_=2.0 * (nf_all + kf_all) * n_samples):

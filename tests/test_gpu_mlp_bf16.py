@@ -123,8 +123,9 @@ def test_mlp_backward_chain_exact_structure(tag, kw, S, n):
     dys = mlp_bf16.mlp_backward(pk, acts, M, ga.cuda().reshape(-1), gb.cuda(), rgbk)
     H, W, D, V = cfg.hidden, cfg.num_samples, pk.D, pk.V
     HP, WP = pk.HT * 32, pk.WT * 32
-    X = [tfrag_to_dense(acts[i], HP if i < 9 else WP, M) for i in range(10)]
-    DY = [tfrag_to_dense(dys[i], HP if i < 9 else WP, M) for i in range(10)]
+    assert acts[8] is None and dys[8] is None               # rgb_net0's output is never formed (folded into rgb_net1)
+    X = [tfrag_to_dense(acts[i], HP if i < 9 else WP, M) if i != 8 else None for i in range(10)]
+    DY = [tfrag_to_dense(dys[i], HP if i < 9 else WP, M) if i != 8 else None for i in range(10)]
     E = tfrag_to_dense(acts[20], pk.DT * 32, M)[:, :D]
     assert torch.equal(E, frag_to_dense(encf, pk.DKS * 16, M)[:, :D])         # the transposition is exact
     VW = tfrag_to_dense(acts[21], pk.VT * 32, M)[:, :V]
@@ -134,9 +135,9 @@ def test_mlp_backward_chain_exact_structure(tag, kw, S, n):
     dz = bf(gb * s * (1 - s))
     r = (dz @ bf(p['final_rgb.0.weight'])) * (X[9][:, :W] > 0)
     assert fro(DY[9][:, :W], r) < 5e-3
-    r = bf(r) @ Wt[9][:, :H]
-    assert fro(DY[8][:, :H], r) < 5e-3
-    r = (bf(r) @ Wt[8] + bf(ga) @ bf(p['final_density.0.weight'])) * (X[7][:, :H] > 0)
+    W8, W9, b8 = p['rgb_net0.0.weight'], p['rgb_net1.0.weight'], p['rgb_net0.0.bias']
+    fold = bf(W9[:, :H] @ W8)                               # fp32 product of the masters, rounded to bf16 once
+    r = (bf(r) @ fold + bf(ga) @ bf(p['final_density.0.weight'])) * (X[7][:, :H] > 0)
     assert fro(DY[7][:, :H], r) < 5e-3
     for i in (6, 5, 4, 3, 2, 1, 0):
         r = (bf(r) @ Wt[i + 1][:, :H]) * (X[i][:, :H] > 0)
@@ -144,11 +145,18 @@ def test_mlp_backward_chain_exact_structure(tag, kw, S, n):
     # weight gradients from the kernel's own fragments
     grads = {nm: torch.zeros_like(v, device='cuda') for nm, v in p.items()}
     mlp_bf16.mlp_weight_grads(pk, acts, dys, M, grads)
-    ins = [E, X[0], X[1], X[2], torch.cat([X[3][:, :H], E], 1), X[4], X[5], X[6], X[7], torch.cat([X[8][:, :H], VW], 1)]
-    for i, nm in enumerate(mlp_bf16.STREAMED):
+    ins = [E, X[0], X[1], X[2], torch.cat([X[3][:, :H], E], 1), X[4], X[5], X[6]]
+    for i, nm in enumerate(mlp_bf16.STREAMED[:8]):
         dy = DY[i][:, :p[nm + '.weight'].shape[0]]
         assert fro(grads[nm + '.weight'].cpu(), dy.t() @ ins[i][:, :p[nm + '.weight'].shape[1]]) < 1e-4, nm
         assert fro(grads[nm + '.bias'].cpu(), dy.sum(0)) < 1e-4, nm
+    # the folded pair: G = dY9^T X7 and s = sum dY9 give both layers' gradients through the fp32 masters
+    dy9 = DY[9][:, :W]
+    G, sm = dy9.t() @ X[7][:, :H], dy9.sum(0)
+    assert fro(grads['rgb_net0.0.weight'].cpu(), W9[:, :H].t() @ G) < 1e-4
+    assert fro(grads['rgb_net0.0.bias'].cpu(), W9[:, :H].t() @ sm) < 1e-4
+    assert fro(grads['rgb_net1.0.weight'].cpu(), torch.cat([G @ W8.t() + sm[:, None] * b8[None], dy9.t() @ VW], 1)) < 1e-4
+    assert fro(grads['rgb_net1.0.bias'].cpu(), sm) < 1e-4
     assert fro(grads['final_rgb.0.weight'].cpu(), dz.t() @ X[9][:, :W]) < 1e-4
     assert fro(grads['final_rgb.0.bias'].cpu(), dz.sum(0)) < 1e-4
     assert fro(grads['final_density.0.weight'].cpu(), bf(ga).t() @ X[7][:, :H]) < 1e-4
