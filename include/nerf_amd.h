@@ -130,6 +130,21 @@ int nerf_composite_bwd(const float* rgb, const float* density, const float* t_va
                        int64_t n_rays, int num_samples, int white_bkgd, const nerf_activation* act,
                        float* g_rgb, float* g_density, void* stream);
 
+/* One level of a training step in one pass: nerf_composite_fwd, the masked squared-error loss of the composited
+ * colour against target[N,3], and nerf_composite_bwd for that loss.  The level's loss upstream is
+ * sum(lossmult * (comp - target)^2) / sum(lossmult), weighted by coarse_weight_decay for the coarse levels
+ * (util_modules.py:61-70); it is separable over rays given the global mask sum, so with inv_mask_sum[0] =
+ * 1 / sum(lossmult) over the WHOLE batch (a device scalar: all ranks' rays) and level_weight the level's factor,
+ * g_rgb[N,S,3] / g_density[N,S] receive dLoss/d(raw inputs) directly.  ray_sq[N] = lossmult * sum_c (comp_c -
+ * target_c)^2 per ray, unscaled: the level's loss is level_weight * inv_mask_sum * sum(ray_sq).  lossmult[N]
+ * nullable (= 1).  weights[N,S] nullable.  num_samples <= 2048.
+ *                             reference: utils.py:299-317, util_modules.py:61-70 and autograd of both */
+int nerf_composite_train(const float* rgb, const float* density, const float* t_vals, const float* dirs,
+                         const float* target, const float* lossmult, const float* inv_mask_sum,
+                         float level_weight, int64_t n_rays, int num_samples, int white_bkgd,
+                         const nerf_activation* act, float* comp_rgb, float* distance, float* acc,
+                         float* weights, float* ray_sq, float* g_rgb, float* g_density, void* stream);
+
 /* ---- (d') SAR scattering + range-bin scatter ------------------------------------------- */
 
 /* One pulse: rgb[R,S,3], angle[R,S,2], density[R,S], power[R], t_vals[R,S+1], dirs[R,3],

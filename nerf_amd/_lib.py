@@ -40,6 +40,8 @@ _SIGS = {
                                    _P, _P, _P, _P, _P, _P]),
     'nerf_composite_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, POINTER(NerfActivation),
                                    _P, _P, _P]),
+    'nerf_composite_train': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int64, c_int, c_int,
+                                     POINTER(NerfActivation), _P, _P, _P, _P, _P, _P, _P, _P]),
     'nerf_scatter_fwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_float,
                                  POINTER(NerfActivation), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'nerf_scatter_fwd_static': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_float,

@@ -224,6 +224,54 @@ __global__ void composite_bwd_kernel(const float* __restrict__ rgb, const float*
                          g_density + ray * S);
 }
 
+// Training form of one level: compositing, the masked squared error of the composited colour against the target
+// pixel, and the backward sweep, in one pass over the ray while its samples are still in LDS / cache.  The loss of
+// the reference, sum(mask * (comp - target)^2) / sum(mask) per level (util_modules.py:61-70), is separable over
+// rays once the global mask sum is known, so dL/dcomp = 2 level_weight mask (comp - target) / sum(mask) needs no
+// second kernel.  ray_sq[ray] = mask * sum_c (comp_c - target_c)^2 (unscaled) goes out for the caller to add up.
+//                                           reference: utils.py:299-317 + util_modules.py:61-70 + their autograd
+__global__ void composite_train_kernel(const float* __restrict__ rgb, const float* __restrict__ density,
+                                       const float* __restrict__ t_vals, const float* __restrict__ dirs,
+                                       const float* __restrict__ target, const float* __restrict__ lossmult,
+                                       const float* __restrict__ inv_mask_sum, float level_weight, int64_t n_rays,
+                                       int S, int white_bkgd, ActParams act, float* __restrict__ comp_rgb,
+                                       float* __restrict__ distance, float* __restrict__ acc,
+                                       float* __restrict__ weights, float* __restrict__ ray_sq,
+                                       float* __restrict__ g_rgb, float* __restrict__ g_density) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (ray >= n_rays) return;
+    float* w_lds = smem + wave * 2 * S;
+    float* te_lds = w_lds + S;
+    const float* t = t_vals + ray * (S + 1);
+    const float dnorm = ray_dnorm(dirs + ray * 3);
+    RaySums<0> r = composite_ray<0>(rgb + ray * S * 3, nullptr, density + ray * S, t, dnorm, S, lane, act,
+                                    weights ? weights + ray * S : nullptr, nullptr, w_lds, te_lds);
+    __builtin_amdgcn_wave_barrier();
+    const float bg = white_bkgd ? (1.f - r.acc) : 0.f;
+    const float mask = lossmult ? lossmult[ray] : 1.f;
+    const float scale = (2.f * level_weight) * mask * inv_mask_sum[0];
+    float gc[3], sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float c = r.c[k] + bg;
+        const float e = c - target[ray * 3 + k];
+        sq += e * e;
+        gc[k] = scale * e;
+        if (lane == 0) comp_rgb[ray * 3 + k] = c;
+    }
+    if (lane == 0) {
+        acc[ray] = r.acc;
+        distance[ray] = expected_distance(r.num, r.acc, t[0], t[S], nullptr);
+        ray_sq[ray] = mask * sq;
+    }
+    const float g_acc = white_bkgd ? -(gc[0] + gc[1] + gc[2]) : 0.f;
+    composite_ray_bwd<0>(rgb + ray * S * 3, nullptr, density + ray * S, t, dnorm, S, lane, act, w_lds, te_lds, gc,
+                         nullptr, 0.f, g_acc, 0.f, 0.f, r.acc, g_rgb + ray * S * 3, nullptr, g_density + ray * S);
+}
+
 // ------------------------------------------------------------------------------------------
 // SAR: reflectance model + two-way phase.                          reference: utils.py:350-376
 struct Reflect {
@@ -439,6 +487,23 @@ extern "C" int nerf_composite_bwd(const float* rgb, const float* density, const 
     hipLaunchKernelGGL(composite_bwd_kernel, dim3(nerf_blocks(n_rays, kWavesPerBlock)), dim3(64 * kWavesPerBlock),
                        lds, nerf_stream(stream), rgb, density, t_vals, dirs, g_comp_rgb, g_distance, g_acc, n_rays,
                        num_samples, white_bkgd, make_act(act), g_rgb, g_density);
+    return nerf_launch_status();
+}
+
+extern "C" int nerf_composite_train(const float* rgb, const float* density, const float* t_vals, const float* dirs,
+                                    const float* target, const float* lossmult, const float* inv_mask_sum,
+                                    float level_weight, int64_t n_rays, int num_samples, int white_bkgd,
+                                    const nerf_activation* act, float* comp_rgb, float* distance, float* acc,
+                                    float* weights, float* ray_sq, float* g_rgb, float* g_density, void* stream) {
+    if (n_rays == 0) return NERF_OK;
+    NERF_REQUIRE(rgb && density && t_vals && dirs && target && inv_mask_sum && comp_rgb && distance && acc && ray_sq &&
+                 g_rgb && g_density && n_rays >= 0 && num_samples >= 1);
+    if (num_samples > kMaxBwdSamples) return NERF_ERR_SIZE;
+    const size_t lds = (size_t)kWavesPerBlock * 2 * num_samples * sizeof(float);
+    hipLaunchKernelGGL(composite_train_kernel, dim3(nerf_blocks(n_rays, kWavesPerBlock)), dim3(64 * kWavesPerBlock),
+                       lds, nerf_stream(stream), rgb, density, t_vals, dirs, target, lossmult, inv_mask_sum,
+                       level_weight, n_rays, num_samples, white_bkgd, make_act(act), comp_rgb, distance, acc, weights,
+                       ray_sq, g_rgb, g_density);
     return nerf_launch_status();
 }
 

@@ -1489,8 +1489,8 @@ static bool wgrad_config(int NT, int KT, int* NW, int* WN, int* WK, int* tn, int
     // {waves, WN, WK} splits and {waves, tn, tk} instantiations; 8 waves (half the registers each) take the
     // outputs too large for 16 accumulator tiles per wave
     static const int kSplit[5][3] = {{4, 2, 2}, {4, 4, 1}, {4, 1, 4}, {8, 2, 4}, {8, 4, 2}};
-    static const int kTmpl[9][3] = {{4, 1, 1}, {4, 1, 2}, {4, 1, 4}, {4, 2, 2}, {4, 2, 4}, {4, 2, 5}, {4, 4, 4},
-                                    {8, 4, 3}, {8, 5, 2}};
+    static const int kTmpl[10][3] = {{4, 1, 1}, {4, 1, 2}, {4, 1, 4}, {4, 2, 2}, {4, 2, 4}, {4, 2, 5}, {4, 4, 4},
+                                     {4, 5, 3}, {8, 4, 3}, {8, 5, 2}};
     int best = 1 << 30;
     *tn = *tk = 0;
     for (const auto& sp : kSplit) {
@@ -1505,7 +1505,8 @@ static bool wgrad_config(int NT, int KT, int* NW, int* WN, int* WK, int* tn, int
 
 // Instantiations with a compile-time load count exist for the shapes of the 8 x 256 network: -> that count, else 0.
 static int wgrad_static_loads(int nw, int tn, int tk, int loads) {
-    static const int kStatic[6][4] = {{4, 4, 4, 4}, {8, 4, 3, 3}, {8, 5, 2, 3}, {4, 2, 5, 4}, {4, 2, 2, 3}, {4, 1, 1, 2}};
+    static const int kStatic[7][4] = {{4, 4, 4, 4}, {8, 4, 3, 3}, {8, 5, 2, 3}, {4, 2, 5, 4}, {4, 2, 2, 3}, {4, 1, 1, 2},
+                                      {4, 5, 3, 4}};
     for (const auto& v : kStatic)
         if (v[0] == nw && v[1] == tn && v[2] == tk && v[3] == loads) return loads;
     return 0;
@@ -1564,6 +1565,7 @@ extern "C" int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples,
     if (const int gt = wgrad_static_loads(nw, tn, tk, loads)) {
         if (nw == 8) return tn == 4 ? launch_wgrad<8, 4, 3, 3>(a, grid, lds, st) : launch_wgrad<8, 5, 2, 3>(a, grid, lds, st);
         if (tn == 4) return launch_wgrad<4, 4, 4, 4>(a, grid, lds, st);
+        if (tn == 5) return launch_wgrad<4, 5, 3, 4>(a, grid, lds, st);
         if (tk == 5) return launch_wgrad<4, 2, 5, 4>(a, grid, lds, st);
         if (tn == 2) return launch_wgrad<4, 2, 2, 3>(a, grid, lds, st);
         (void)gt;
@@ -1576,6 +1578,7 @@ extern "C" int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples,
     if (tn == 2 && tk == 2) return launch_wgrad<4, 2, 2>(a, grid, lds, st);
     if (tn == 2 && tk == 4) return launch_wgrad<4, 2, 4>(a, grid, lds, st);
     if (tn == 2 && tk == 5) return launch_wgrad<4, 2, 5>(a, grid, lds, st);
+    if (tn == 5 && tk == 3) return launch_wgrad<4, 5, 3>(a, grid, lds, st);
     return launch_wgrad<4, 4, 4>(a, grid, lds, st);
 }
 

@@ -189,16 +189,35 @@ def view_frag(dirs, min_deg, max_deg):
     return out
 
 
-def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False):
-    """-> raw_density [M], raw_rgb [M,3], raw_angle [M,2] or None, acts (list of byte buffers) or None."""
+def act_block_bytes(pk):
+    """Bytes per block of 64 samples of each buffer the forward chain saves (index as in `acts`; None = unused)."""
+    tiles = [pk.HT] * 9 + [pk.WT]
+    per = [t * 4096 if i != 8 else None for i, t in enumerate(tiles)]
+    per += [2 * ((t + 1) // 2) * 256 if i != 8 else None for i, t in enumerate(tiles)]
+    per += [pk.DT * 4096, pk.VT * 4096]
+    if pk.sar:
+        per.append(32 * pk.HT * 128)
+    return per
+
+
+def dy_block_bytes(pk):
+    """Bytes per block of 64 samples of each dY buffer of the backward chain (None = unused)."""
+    return [t * 4096 if i != 8 else None for i, t in enumerate([pk.HT] * 9 + [pk.WT, 1, 1])]
+
+
+def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False, acts=None, raw=None):
+    """-> raw_density [M], raw_rgb [M,3], raw_angle [M,2] or None, acts (list of byte buffers) or None.
+    `acts` (buffers laid out as act_block_bytes says) and `raw = (raw_density, raw_rgb)` may be supplied by a
+    caller that owns persistent buffers; otherwise they are allocated here."""
     dev = enc.device
     nblk = n_blocks(n_samples)
-    raw_density = torch.empty(n_samples, device=dev)
-    raw_rgb = torch.empty(n_samples, 3, device=dev)
+    raw_density, raw_rgb = raw if raw is not None else (torch.empty(n_samples, device=dev), torch.empty(n_samples, 3, device=dev))
     raw_angle = torch.empty(n_samples, 2, device=dev) if pk.sar else None
     ln_stats = torch.empty(n_samples, 2, device=dev) if (pk.sar and save) else None
-    acts = arr = None
-    if save:
+    arr = None
+    if acts is not None:
+        arr = (c_void_p * len(acts))(*[a.data_ptr() if a is not None else None for a in acts])
+    elif save:
         # 0..9 X0..X7, X9 as T-frags (8 unused: rgb_net0's output is never formed), 10..19 their ReLU sign words,
         # 20 enc, 21 view T-frags
         tiles = [pk.HT] * 9 + [pk.WT]
@@ -210,7 +229,7 @@ def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False):
         if pk.sar:       # 22: the trunk output once more in frag order, for the LayerNorm backward
             acts.append(torch.empty(nblk * 32 * pk.HT * 128, dtype=torch.uint8, device=dev))
         arr = (c_void_p * len(acts))(*[a.data_ptr() if a is not None else None for a in acts])
-    saved = sum(a.numel() for a in acts if a is not None) if save else 0         # bytes the launch writes for the backward pass
+    saved = sum(a.numel() for a in acts if a is not None) if acts is not None else 0   # bytes the launch writes for the backward pass
     with profiling.timed('mlp_fwd_kernel', flops=pk.fwd_flops * n_samples, bytes_=float(saved)):
         check(lib().nerf_mlp_fwd(ctypes.byref(pk.dims), _raw(pk.wfwd), ptr(pk.consts), _raw(enc), _raw(view),
                                  n_samples, ray_div, n_rays, arr, ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
@@ -219,19 +238,21 @@ def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False):
 
 
 def mlp_backward(pk, acts, n_samples, g_density, g_rgb, raw_rgb, g_angle=None, raw_density=None, raw_angle=None,
-                 ln_stats=None):
+                 ln_stats=None, dys=None, n_real=None):
     """Backward chain -> list of 12 dY T-frag buffers (dY0..dY9, colour head tile, density head tile).
-    The SAR heads also need the angle gradient and the forward's density / angle outputs and LayerNorm statistics."""
+    The SAR heads also need the angle gradient and the forward's density / angle outputs and LayerNorm statistics.
+    `dys` may be supplied (dy_block_bytes layout); `n_real` is the sample count the work is accounted for."""
     dev = g_density.device
     nblk = n_blocks(n_samples)
     tiles = [pk.HT] * 9 + [pk.WT, 1, 1]
-    dys = [torch.empty(nblk * t * 4096, dtype=torch.uint8, device=dev) if i != 8 else None for i, t in enumerate(tiles)]
+    if dys is None:
+        dys = [torch.empty(nblk * t * 4096, dtype=torch.uint8, device=dev) if i != 8 else None for i, t in enumerate(tiles)]
     a_arr = (c_void_p * len(acts))(*[a.data_ptr() if a is not None else None for a in acts])
     d_arr = (c_void_p * 12)(*[d.data_ptr() if d is not None else None for d in dys])
     g_density, g_rgb = f32c(g_density).reshape(-1), f32c(g_rgb).reshape(-1, 3)
     if pk.sar:
         g_angle = f32c(g_angle).reshape(-1, 2)
-    with profiling.timed('mlp_bwd_kernel', flops=pk.bwd_dx_flops * n_samples, bytes_=float(sum(d.numel() for d in dys if d is not None))):
+    with profiling.timed('mlp_bwd_kernel', flops=pk.bwd_dx_flops * (n_real or n_samples), bytes_=float(sum(d.numel() for d in dys if d is not None))):
         check(lib().nerf_mlp_bwd(ctypes.byref(pk.dims), _raw(pk.wbwd), ptr(pk.consts), n_samples, ptr(g_density),
                                  ptr(g_rgb), ptr(g_angle), ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
                                  ptr(ln_stats), a_arr, d_arr, stream()))

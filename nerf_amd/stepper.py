@@ -1,0 +1,143 @@
+"""One mip-NeRF training step as a fixed sequence of kernel launches on persistent buffers, without autograd.
+
+What the reference does in `training_step` (model.py:185-191: forward over the levels, model.py:100-151; the
+masked MSE, util_modules.py:58-71; `manual_backward`; optimizer step) is here one hand-ordered pass:
+
+    per level:  fenceposts (stratified / resampled)  ->  cast + integrated encoding as operand fragments
+                ->  forward chain (saves what the backward pass reads)
+                ->  compositing + loss + compositing backward in one kernel
+    then:       ONE backward chain over the samples of all levels
+                ->  ONE weight-gradient launch per layer over the samples of all levels, adding into the flat
+                    gradient bucket  ->  (all-reduce)  ->  optimizer  ->  weight repack
+
+The levels' samples lie behind one another in every saved buffer (level l starts at a whole 256-sample workgroup
+tile), so the passes that do not depend on the level order -- the input-gradient chain and the weight gradients --
+run once per step instead of once per level.  Every buffer is allocated once for a given batch geometry.
+"""
+import ctypes
+from ctypes import c_void_p
+
+import torch
+
+from . import mlp_bf16
+from ._lib import NerfActivation, check, lib, ptr, stream
+
+_EPS32 = float(torch.finfo(torch.float32).eps)
+
+
+def supported(model):
+    """The fused step covers the view-dependent bf16 network without density noise (model.py:135-136 draws noise
+    between the MLP and the compositing; that variant goes through autograd)."""
+    cfg = model.config
+    return (getattr(cfg, 'mlp_precision', 'fp32') == 'bf16' and model.use_viewdirs
+            and not (model.randomized and model.density_noise) and not getattr(model, 'return_raw', False)
+            and hasattr(model, 'white_bkgd'))
+
+
+class NerfStepper:
+    """Persistent buffers + launch sequence for `n_rays` rays per step at the model's level sample counts."""
+
+    def __init__(self, model, n_rays):
+        self.model, self.n = model, int(n_rays)
+        cfg = model.config
+        self.levels = model._level_samples()
+        self.dev = dev = model.device
+        pk = mlp_bf16.packed_for(model, need_bwd=True)
+        n = self.n
+        self.nblk = [mlp_bf16.n_blocks(n * S) for S in self.levels]
+        self.blk0 = [sum(self.nblk[:l]) for l in range(len(self.levels))]
+        self.nblk_total = sum(self.nblk)
+        u8 = lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        self.act_bytes = mlp_bf16.act_block_bytes(pk)
+        self.dy_bytes = mlp_bf16.dy_block_bytes(pk)
+        self.acts = [u8(self.nblk_total * b) if b is not None else None for b in self.act_bytes]
+        self.dys = [u8(self.nblk_total * b) if b is not None else None for b in self.dy_bytes]
+        # per-sample fp32 arrays, level after level at the same block offsets; the padding samples of a level's
+        # last tile are never written, so they are zeroed once: a zero gradient there keeps them out of every sum
+        m_all = 64 * self.nblk_total
+        self.raw_density, self.raw_rgb = torch.zeros(m_all, device=dev), torch.zeros(m_all, 3, device=dev)
+        self.g_density, self.g_rgb = torch.zeros(m_all, device=dev), torch.zeros(m_all, 3, device=dev)
+        dks = pk.DKS
+        self.enc = [u8(nb * dks * 2 * 1024) for nb in self.nblk]
+        self.view = u8(n * pk.VKS * 2 * 16)
+        self.t_vals = [f32(n, S + 1) for S in self.levels]
+        self.rand = [f32(n, S + 1) for S in self.levels]
+        self.weights = [f32(n, S) for S in self.levels]
+        L = len(self.levels)
+        self.comp, self.dist, self.acc = f32(L, n, 3), f32(L, n), f32(L, n)
+        self.ray_sq = f32(L, n)
+        self.inv_mask_sum = f32(1)
+
+    # ---- helpers ---------------------------------------------------------------------------
+    def _level(self, bufs, per_block, l):
+        lo, hi = self.blk0[l], self.blk0[l] + self.nblk[l]
+        return [b[lo * pb:hi * pb] if b is not None else None for b, pb in zip(bufs, per_block)]
+
+    def _samples(self, t, l):
+        S = self.levels[l]
+        lo = 64 * self.blk0[l]
+        return t[lo:lo + self.n * S]
+
+    def step(self, rays, pixels, global_mask_sum=None, t_rand=None, u_rand=None):
+        """Forward + loss + backward of one batch; the weight gradients are ADDED into the parameters' `.grad`
+        (views of the caller's gradient bucket).  -> loss (device scalar), comp_rgb [L,N,3] (this step's buffers)."""
+        model, n, dev = self.model, self.n, self.dev
+        cfg = model.config
+        assert rays.origins.shape[0] == n
+        pk = mlp_bf16.packed_for(model, need_bwd=True)
+        L_ = lib()
+        st = stream()
+        f = lambda t, *shape: t.detach().to(torch.float32).reshape(*shape).contiguous()
+        o, d, vd = f(rays.origins, n, 3), f(rays.directions, n, 3), f(rays.viewdirs, n, 3)
+        radii, near, far = f(rays.radii, n), f(rays.near, n), f(rays.far, n)
+        lossmult, target = f(rays.lossmult, n), f(pixels, n, 3)
+        if global_mask_sum is None:
+            global_mask_sum = lossmult.sum()
+        torch.reciprocal(torch.as_tensor(global_mask_sum, dtype=torch.float32, device=dev).reshape(1), out=self.inv_mask_sum)
+        check(L_.nerf_view_frag(ptr(vd), n, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg, c_void_p(self.view.data_ptr()), st))
+        act = ctypes.byref(NerfActivation(1, float(model.rgb_padding), float(model.density_bias)))
+        cwd = float(model.loss_function.coarse_weight_decay)
+        nl = len(self.levels)
+        shape = mlp_bf16.RAY_SHAPES[model.ray_shape]
+        for l, S in enumerate(self.levels):
+            t = self.t_vals[l]
+            if l == 0:                                                          # utils.py:214-228
+                r = None
+                if model.randomized:
+                    r = f(t_rand, n, S + 1) if t_rand is not None else torch.rand(n, S + 1, out=self.rand[0])
+                check(L_.nerf_stratified_t(ptr(near), ptr(far), ptr(r), n, S, 0, ptr(t), st))
+            else:                                                               # utils.py:252-264, 16-63
+                r = None
+                if model.randomized:
+                    r = (f(u_rand[l], n, S + 1) if u_rand is not None else
+                         self.rand[l].uniform_(0, 1 / (S + 1) - _EPS32))
+                S0 = self.levels[l - 1]
+                check(L_.nerf_resample(ptr(self.t_vals[l - 1]), ptr(self.weights[l - 1]), ptr(r), n, S0, S + 1,
+                                       float(model.resample_padding), 1, ptr(t), None, None, st))
+            check(L_.nerf_encode_frag(ptr(t), ptr(o), ptr(d), ptr(radii), n, S, shape, cfg.min_deg, cfg.max_deg,
+                                      c_void_p(self.enc[l].data_ptr()), st))
+            raw_d, raw_c = self._samples(self.raw_density, l), self._samples(self.raw_rgb, l)
+            mlp_bf16.mlp_forward(pk, self.enc[l], self.view, n * S, S, n, acts=self._level(self.acts, self.act_bytes, l),
+                                 raw=(raw_d, raw_c))
+            check(L_.nerf_composite_train(ptr(raw_c), ptr(raw_d), ptr(t), ptr(d), ptr(target), ptr(lossmult),
+                                          ptr(self.inv_mask_sum), 1.0 if l == nl - 1 else cwd, n, S,
+                                          int(bool(model.white_bkgd)), act, ptr(self.comp[l]), ptr(self.dist[l]),
+                                          ptr(self.acc[l]), ptr(self.weights[l]), ptr(self.ray_sq[l]),
+                                          ptr(self._samples(self.g_rgb, l)), ptr(self._samples(self.g_density, l)), st))
+        m_all = 64 * self.nblk_total
+        n_real = n * sum(self.levels)
+        mlp_bf16.mlp_backward(pk, self.acts, m_all, self.g_density, self.g_rgb, self.raw_rgb, dys=self.dys, n_real=n_real)
+        grads = {k: q.grad for k, q in model.named_parameters() if q.requires_grad}
+        mlp_bf16.mlp_weight_grads(pk, self.acts, self.dys, m_all, grads)
+        sq = self.ray_sq.sum(dim=1) * self.inv_mask_sum
+        return cwd * sq[:-1].sum() + sq[-1], self.comp
+
+
+def stepper_for(model, n_rays):
+    s = getattr(model, '_stepper', None)
+    if s is None or s.n != n_rays or s.levels != model._level_samples() or s.dev != model.device:
+        model._stepper = None           # release the old buffers before the new ones are allocated
+        s = NerfStepper(model, n_rays)
+        model._stepper = s
+    return s

@@ -102,12 +102,18 @@ def shard_range(n, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def nerf_train_step(model, rays, pixels, optimizer, chunk=8192, world_size=1, global_mask_sum=None, scheduler=None):
+def nerf_train_step(model, rays, pixels, optimizer, chunk=8192, world_size=1, global_mask_sum=None, scheduler=None,
+                    fused=True):
     """fwd + bwd (+ all-reduce) + optimizer step on this rank's rays.
 
     The loss is sum(mask * err^2) / sum(mask) over the GLOBAL batch (util_modules.py:65), so each
     chunk contributes its masked squared-error sum divided by the global mask sum; gradients then
-    add up across chunks and ranks."""
+    add up across chunks and ranks.
+
+    When the batch is one chunk and the model runs the bf16 chain, the step is the fixed launch sequence of
+    `nerf_amd.stepper` (no autograd, persistent buffers, one backward chain and one weight-gradient pass for all
+    levels); otherwise (`fused=False`, several chunks, the fp32 path, density noise) it goes through autograd
+    chunk by chunk.  Both accumulate into the same gradient bucket."""
     bucket = grad_bucket(model)
     n = rays.origins.shape[0]
     if global_mask_sum is None:             # the denominator of the reference loss is the mask sum of the WHOLE batch
@@ -116,6 +122,10 @@ def nerf_train_step(model, rays, pixels, optimizer, chunk=8192, world_size=1, gl
             global_mask_sum = global_mask_sum.clone()
             _all_reduce_sum(global_mask_sum)
     bucket.zero()
+    from . import stepper
+    if fused and chunk >= n and n > 0 and stepper.supported(model):
+        total, _ = stepper.stepper_for(model, n).step(rays, pixels, global_mask_sum)
+        return _finish_step(model, bucket, optimizer, scheduler, world_size, total)
     total = torch.zeros((), device=rays.origins.device)
     cwd = model.loss_function.coarse_weight_decay
     import contextlib
@@ -131,6 +141,10 @@ def nerf_train_step(model, rays, pixels, optimizer, chunk=8192, world_size=1, gl
             loss = cwd * sq[:-1].sum() + sq[-1]
             loss.backward()
             total += loss.detach()
+    return _finish_step(model, bucket, optimizer, scheduler, world_size, total)
+
+
+def _finish_step(model, bucket, optimizer, scheduler, world_size, total):
     bucket.attach()
     work = bucket.all_reduce(world_size, async_op=True)
     if work is not None:
