@@ -253,6 +253,17 @@ int nerf_encode_frag(const float* t_vals, const float* origins, const float* dir
  *                                              reference: util_modules.py:49, model.py:125-126 */
 int nerf_view_frag(const float* dirs, int64_t n_rays, int min_deg, int max_deg, void* out, void* stream);
 
+/* Storage format of the transposed fragments that the chain kernels save for the weight-gradient pass (the chain
+ * itself always computes in bf16 with fp32 accumulation):
+ *   NERF_TFRAG_BF16  bf16, 128 bytes per sample per 64 features;
+ *   NERF_TFRAG_E4M3  OCP e4m3, 64 bytes per sample per 64 features; gradient buffers carry one power-of-two scale
+ *                    per (feature, block of 32 samples) in a side array of 8 bytes per sample block and feature row
+ *                    (the MX block-scale layout of the matrix cores along the reduction axis), activations are
+ *                    stored unscaled.  Halves the bytes the training step moves; the weight gradients differ from
+ *                    the bf16-operand ones by 1e-3 .. 7e-3 relative (Frobenius) on a 196 608-sample batch. */
+#define NERF_TFRAG_BF16 0
+#define NERF_TFRAG_E4M3 1
+
 /* Forward chain for n_samples rows: raw_density[M], raw_rgb[M,3] (after the sigmoid),
  * raw_angle[M,2] (SAR).  Row m takes the view features of ray m / ray_div (NeRF, ray_div = samples
  * per ray) or m % ray_div (SAR, ray_div = rays per chunk -- the row order upstream produces,
@@ -262,10 +273,11 @@ int nerf_view_frag(const float* dirs, int64_t n_rays, int min_deg, int max_deg, 
  * output is never formed), [10..19] their ReLU sign words (nblk * 2 *
  * ceil(features / 64) * 256 bytes; [18] unused, may be NULL), [20] / [21] the position encoding and
  * view features as transposed fragments, [22] (SAR only) the trunk output in fragment order (nblk * H_padded
- * * 128 bytes).                                        reference: model.py:117-132, 343-359 */
+ * * 128 bytes).  With tfrag_fmt = NERF_TFRAG_E4M3 the transposed-fragment buffers [0..9], [20], [21] hold e4m3 and
+ * need half the bytes.                                 reference: model.py:117-132, 343-359 */
 int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* consts, const void* enc_frag,
                  const void* view_frag, int64_t n_samples, int ray_div, int64_t n_rays, void* const* acts,
-                 float* raw_density, float* raw_rgb, float* raw_angle, float* ln_stats, void* stream);
+                 int tfrag_fmt, float* raw_density, float* raw_rgb, float* raw_angle, float* ln_stats, void* stream);
 
 /* Backward chain of the fused MLP: from dL/d raw_density [M], dL/d raw_rgb [M,3] (w.r.t. the
  * post-sigmoid output; raw_rgb is that saved output) through every layer, writing dL/d(layer
@@ -275,12 +287,14 @@ int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* const
  * nerf_mlp_fwd saved (only the ReLU sign words acts[10..19] are read; SAR also acts[22]).  SAR heads
  * (model.py:278-302): g_angle [M,2], raw_angle, raw_density (the forward's outputs), ln_stats and the forward
  * constants block are required too; the density head tile then carries rows g*rstd, g*rstd*mean, g, from which
- * the LayerNorm and density-weight gradients are assembled (NeRF: pass NULL for them).
+ * the LayerNorm and density-weight gradients are assembled (NeRF: pass NULL for them).  With tfrag_fmt =
+ * NERF_TFRAG_E4M3 every dys[i] holds e4m3 (half the bytes) and dys[12 + i] (nblk * 2 * 256 bytes each) receives
+ * its scale bytes.
  *                              reference: autograd of model.py:117-132 (aten::mm, threshold_backward) */
 int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, const float* consts, int64_t n_samples,
                  const float* g_density, const float* g_rgb, const float* g_angle, const float* raw_density,
                  const float* raw_rgb, const float* raw_angle, const float* ln_stats, void* const* acts,
-                 void* const* dys, void* stream);
+                 void* const* dys, int tfrag_fmt, void* stream);
 
 /* Weight / bias gradient of one linear layer from transposed fragments: G[n, col0 + k] += sum_m dY[m,n] X[m,k]
  * (n < n_true, k < k_true; G is fp32 [n_true, ld]) and gb[n] += sum_m dY[m,n] (gb nullable).
@@ -296,7 +310,7 @@ int nerf_mlp_wgrad(const void* dy_tfrag, int n_feat, const void* x_tfrag, int k_
  * [dY of rgb_net0 | dY of final_density] against the trunk output.  Block (i, j) accumulates
  * G[i][j][n, col0[i][j] + k] += sum_m dy[i][m, n] x[j][m, k] for n < dy_true[i], k < x_true[j] (G[i][j] NULL = skip);
  * gb[i][n] += sum_m dy[i][m, n] (nullable).  Feature counts are padded (multiples of 32); unused second
- * segments have feature count 0.  Total dY + X features <= 576.
+ * segments have feature count 0.  Total dY + X features <= 576; in the e4m3 format a dY segment has <= 256 features.
  *                              reference: autograd of nn.Linear (aten::mm of dY^T and X, aten::sum) */
 typedef struct nerf_wgrad_desc {
     const void* dy[2];
@@ -306,6 +320,8 @@ typedef struct nerf_wgrad_desc {
     float* G[2][2];
     int ld[2][2], col0[2][2];
     float* gb[2];
+    int tfrag_fmt;             /* NERF_TFRAG_BF16 or NERF_TFRAG_E4M3: the format of dy[] and x[] */
+    const void* dy_scale[2];   /* NERF_TFRAG_E4M3: the scale bytes of dy[] (what nerf_mlp_bwd wrote beside them) */
 } nerf_wgrad_desc;
 int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint, void* stream);
 
@@ -313,6 +329,8 @@ int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_h
  * counts uses (gt = compile-time loads per wave and k-step, 0 = run-time count), so a profiler can label launches
  * by kernel symbol.  (No reference counterpart: measurement support.) */
 int nerf_mlp_wgrad_config(int n_feat, int k_feat, int* nw, int* tn, int* tk, int* gt);
+/* The same for NERF_TFRAG_E4M3 launches: mlp_wgrad8_kernel<tn, tk>. */
+int nerf_mlp_wgrad8_config(int n_feat, int k_feat, int* tn, int* tk);
 
 #ifdef __cplusplus
 }

@@ -121,6 +121,65 @@ __device__ __forceinline__ void emit_tfrag(bf16x8* dst, int64_t b32, int NT, int
     }
 }
 
+// ---- 8-bit transposed fragments ("T-frag8") ----------------------------------------------------------------
+// The weight-gradient operands may be kept as OCP e4m3 instead of bf16 (half the bytes written by the chain kernels
+// and read by the weight-gradient pass; the chain itself stays bf16).  Layout of a buffer of F = 32 T features:
+//   data   [block of 32 samples][T tiles][64 lanes][16 bytes]: lane 32*hh + n holds feature n of the tile, byte r is
+//          sample (r & 3) + 8 (r >> 2) + 4 hh of the block -- the 16 accumulator registers of the transposing MFMAs as
+//          they stand, one 1 KiB piece per (block, tile);
+//   scales [block of 32 samples][32 features n][8 bytes] (gradient buffers only): byte t is the E8M0 exponent e of
+//          (block, tile t, feature n): stored value = true value * 2^(127 - e), e chosen so that the block's largest
+//          magnitude lands in [128, 256).  One exponent per (feature, 32 samples) is the MX block of
+//          v_mfma_scale_f32_32x32x64_f8f6f4 along its reduction axis.  Activations are stored unscaled (e = 127).
+__device__ __forceinline__ u32x4 pack_fp8x16(const f32x16& t) {
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(t[4 * q], t[4 * q + 1], 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(t[4 * q + 2], t[4 * q + 3], w, true);
+        o[q] = (unsigned)w;
+    }
+    return o;
+}
+__device__ __forceinline__ f32x16 transpose_tile(bf16x8 p0, bf16x8 p1, const bf16x8 (&P)[2]) {
+    f32x16 t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = 0.f;
+    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p0, P[0], t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, P[1], t, 0, 0, 0);
+    return t;
+}
+// activations: unscaled e4m3
+__device__ __forceinline__ void emit_tfrag8(void* dst, int64_t b32, int NT, int nt, int lane, bf16x8 p0, bf16x8 p1,
+                                            const bf16x8 (&P)[2]) {
+    const f32x16 t = transpose_tile(p0, p1, P);
+    __builtin_nontemporal_store(pack_fp8x16(t), (u32x4*)dst + (b32 * NT + nt) * 64 + lane);
+}
+// gradients: block-scaled e4m3; returns the E8M0 exponent of this lane's feature
+__device__ __forceinline__ unsigned emit_tfrag8_scaled(void* dst, int64_t b32, int NT, int nt, int lane, bf16x8 p0,
+                                                        bf16x8 p1, const bf16x8 (&P)[2]) {
+    f32x16 t = transpose_tile(p0, p1, P);
+    float amax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(t[r]));
+    amax = fmaxf(amax, __shfl_xor(amax, 32));                       // the other 16 samples of the block
+    const int field = (int)(__float_as_uint(amax) >> 23);            // biased exponent of the largest magnitude
+    const unsigned e = (unsigned)(field > 7 ? field - 7 : 0);
+    const float inv = __uint_as_float((254u - e) << 23);             // 2^(127 - e): largest magnitude -> [128, 256)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] *= inv;
+    __builtin_nontemporal_store(pack_fp8x16(t), (u32x4*)dst + (b32 * NT + nt) * 64 + lane);
+    return e;
+}
+// the exponents of up to 8 tiles of one block, by the lower lane half (both halves hold the same values)
+__device__ __forceinline__ void store_scales(void* sc, int64_t b32, int lane, unsigned lo, unsigned hi) {
+    if (lane < 32) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 v = {lo, hi};
+        *((u32x2*)sc + b32 * 32 + lane) = v;
+    }
+}
+
 // Slots of the weight ring in LDS.  A stage's weights are fetched kRing-1 stages ahead; because a wave's
 // vector-memory operations retire in order, that is also how many stages an activation store may take to
 // complete before it holds up a weight fetch queued behind it.
@@ -138,10 +197,12 @@ constexpr int stage_count(int tiles) { return (tiles + kTPS - 1) / kTPS; }
 // ------------------------------------------------------------------------------------------------
 // Network geometry (compile time).  HT/WT: 32-row tiles of the hidden width / colour-layer width;
 // DKS/VKS: 16-feature k-steps of the (padded) position / view encodings.
-template <int HT_, int WT_, int DKS_, int VKS_, bool SAR_>
+// F8: the saved weight-gradient operands are T-frag8 (e4m3) instead of bf16 T-frags.
+template <int HT_, int WT_, int DKS_, int VKS_, bool SAR_, bool F8_ = false>
 struct Net {
     static constexpr int HT = HT_, WT = WT_, DKS = DKS_, VKS = VKS_;
-    static constexpr bool SAR = SAR_;
+    static constexpr bool SAR = SAR_, F8 = F8_;
+    static constexpr int TPIECES = F8_ ? 1 : 2;          // stores of one finished tile's transposed copy
     static constexpr int HKS = 2 * HT, WKS = 2 * WT, HP = 32 * HT, WP = 32 * WT;
     static constexpr int NHEAD = SAR ? 5 : 3;            // rgb (3) [+ angle (2)]
     // fp32 constants block (floats): biases, laid out per 32-row tile like the accumulators read them
@@ -213,7 +274,7 @@ constexpr StageDesc fwd_stage(int i) {
     const int kind[kL] = {2, 2, 2, 2, 2, 2, 2, N::SAR ? 3 : 2, 0, 2, 0};
     // stores that finishing tile t of layer l issues: 2 T-frag pieces, + the sign word after every second tile
     auto tile_stores = [&](int l, int t) {
-        return (!SAVE || kind[l] == 0) ? 0 : 2 + ((kind[l] >= 2 && ((t & 1) || t + 1 == tiles[l])) ? 1 : 0) + (kind[l] == 3 ? 2 : 0);
+        return (!SAVE || kind[l] == 0) ? 0 : N::TPIECES + ((kind[l] >= 2 && ((t & 1) || t + 1 == tiles[l])) ? 1 : 0) + (kind[l] == 3 ? 2 : 0);
     };
     if (i < 0) return {0, 0, 0, 0};
     for (int l = 0; l < kL; ++l) {
@@ -228,7 +289,8 @@ constexpr StageDesc fwd_stage(int i) {
     return {0, 0, 0, 0};
 }
 // Backward layers: heads^T (WT tiles, 1 k-step), folded colour layer^T + density row (HT, WKS+1), 7 x (HT, HKS).
-// Finishing a tile stores 2 T-frag pieces; the first stage of a layer also loads the next masked layer's sign words.
+// Finishing a tile stores its transposed copy (2 bf16 pieces or 1 e4m3 piece; the e4m3 form adds one store of the
+// layer's scale bytes behind the last tile); the first stage of a layer also loads the next masked layer's sign words.
 template <class N>
 constexpr StageDesc bwd_stage(int i) {
     constexpr int kL = 9;
@@ -240,7 +302,8 @@ constexpr StageDesc bwd_stage(int i) {
         if (i < stage_count(tiles[l])) {
             const int t0 = i * kTPS, t1 = t0 + kTPS < tiles[l] ? t0 + kTPS : tiles[l];
             int st = 0;
-            for (int t = t0; t < t1; ++t) st += t > 0 ? 2 : 0;
+            for (int t = t0; t < t1; ++t) st += t > 0 ? N::TPIECES : 0;
+            // (the previous layer's last tile: 2 bf16 pieces, or 1 e4m3 piece + the scale bytes)
             return {ks[l] * (t1 - t0), (i == 0 && l > 0) ? 2 : 0, (i == 0 && masked[l + 1]) ? (tiles[l + 1] + 1) / 2 : 0, st};
         }
         i -= stage_count(tiles[l]);
@@ -428,7 +491,10 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
             if (RELU) o = relu_bf16(o);
             out[2 * nt + s] = o;
         }
-        if (SAVE) emit_tfrag(tsave, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
+        if (SAVE) {
+            if constexpr (N::F8) emit_tfrag8(tsave, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
+            else emit_tfrag(tsave, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
+        }
         if (SAVE && EPI == EPI_TRUNK && N::SAR) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -505,11 +571,17 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) zero[j] = (__bf16)0.f;
 #pragma unroll
-        for (int i = 0; i < (N::DKS + 1) / 2; ++i)
-            emit_tfrag(a.t_enc, b32, (N::DKS + 1) / 2, i, lane, enc[2 * i], 2 * i + 1 < N::DKS ? enc[2 * i + 1 < N::DKS ? 2 * i + 1 : 0] : zero, P);
+        for (int i = 0; i < (N::DKS + 1) / 2; ++i) {
+            const bf16x8 hi = 2 * i + 1 < N::DKS ? enc[2 * i + 1 < N::DKS ? 2 * i + 1 : 0] : zero;
+            if constexpr (N::F8) emit_tfrag8(a.t_enc, b32, (N::DKS + 1) / 2, i, lane, enc[2 * i], hi, P);
+            else emit_tfrag(a.t_enc, b32, (N::DKS + 1) / 2, i, lane, enc[2 * i], hi, P);
+        }
 #pragma unroll
-        for (int i = 0; i < (N::VKS + 1) / 2; ++i)
-            emit_tfrag(a.t_view, b32, (N::VKS + 1) / 2, i, lane, view[2 * i], 2 * i + 1 < N::VKS ? view[2 * i + 1 < N::VKS ? 2 * i + 1 : 0] : zero, P);
+        for (int i = 0; i < (N::VKS + 1) / 2; ++i) {
+            const bf16x8 hi = 2 * i + 1 < N::VKS ? view[2 * i + 1 < N::VKS ? 2 * i + 1 : 0] : zero;
+            if constexpr (N::F8) emit_tfrag8(a.t_view, b32, (N::VKS + 1) / 2, i, lane, view[2 * i], hi, P);
+            else emit_tfrag(a.t_view, b32, (N::VKS + 1) / 2, i, lane, view[2 * i], hi, P);
+        }
     }
     __syncthreads();
 
@@ -594,6 +666,7 @@ struct MlpBwdArgs {
     bf16x8* tdy[10];           // dY0..dY7, dY9 as T-frags (index 8 unused)
     bf16x8* tdy_hd;            // 1-tile T-frag of dL/d(pre-sigmoid colour outputs), rows 0..4
     bf16x8* tdy_dens;          // 1-tile T-frag of dL/d raw_density (row 0); SAR rows 0..2: g*rstd, g*rstd*mean, g
+    void* tsc[12];             // e4m3 form: scale bytes of tdy[0..9], tdy_hd, tdy_dens
 };
 
 // One backward layer: NT output tiles (features of the layer INPUT), reduction over KS_M k-steps of
@@ -603,10 +676,12 @@ struct MlpBwdArgs {
 template <class N, int STAGE0, int NT, int KS_M, int KS_E, bool MASKED, int NW_NEXT, bool LNFIX = false, int KM, int KE, int KO, int KW, int KWN, int KX = 1>
 __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[KM], const bf16x8 (&ge)[KE],
                                           bf16x8 (&out)[KO], const unsigned (&keepw)[KW], const unsigned* next_mask,
-                                          unsigned (&nextw)[KWN], bf16x8* tdy, int64_t b32, const bf16x8 (&P)[2],
-                                          const bf16x8 (&x7)[KX] = {}, float c0 = 0.f, float c1 = 0.f) {
+                                          unsigned (&nextw)[KWN], bf16x8* tdy, void* tsc, int64_t b32,
+                                          const bf16x8 (&P)[2], const bf16x8 (&x7)[KX] = {}, float c0 = 0.f,
+                                          float c1 = 0.f) {
     constexpr int KS = KS_M + KS_E;
     const int lane = pipe.lane;
+    unsigned sc_lo = 0, sc_hi = 0;          // e4m3 form: the scale bytes of this layer's tiles
 #define NERF_BS(i) bwd_stage<N>(i)
     constexpr int NS = stage_count(NT);
     static_assert(NERF_BS(STAGE0).ks == KS * (NT < kTPS ? NT : kTPS) && NERF_BS(STAGE0).xloads == NW_NEXT,
@@ -626,7 +701,13 @@ __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[K
             if (MASKED) o = piece_apply_keep(o, ~keepw[MASKED ? nt >> 1 : 0] >> (8 * (nt & 1)), s);
             out[2 * nt + s] = o;
         }
-        emit_tfrag(tdy, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
+        if constexpr (N::F8) {
+            const unsigned e = emit_tfrag8_scaled(tdy, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
+            if constexpr (nt < 4) sc_lo |= e << (8 * nt);
+            else sc_hi |= e << (8 * (nt - 4));
+        } else {
+            emit_tfrag(tdy, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
+        }
     };
     f32x16 prev;
     static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
@@ -661,6 +742,7 @@ __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[K
         pipe.template arrive<bwd_younger<N>(STAGE0 + st)>();
     });
     finish(IC<NT - 1>{}, prev);
+    if constexpr (N::F8) store_scales(tsc, b32, lane, sc_lo, sc_hi);
 #undef NERF_BS
 }
 
@@ -726,8 +808,13 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
     unsigned kw9[WW], kwa[HW], kwb[HW], nokw[1] = {0u};
 #pragma unroll
     for (int i = 0; i < WW; ++i) kw9[i] = a.mask[9][(b32 * WW + i) * 64 + lane];
-    emit_tfrag(a.tdy_hd, b32, 1, 0, lane, dz, zero, P);
-    emit_tfrag(a.tdy_dens, b32, 1, 0, lane, dd, zero, P);
+    if constexpr (N::F8) {
+        store_scales(a.tsc[10], b32, lane, emit_tfrag8_scaled(a.tdy_hd, b32, 1, 0, lane, dz, zero, P), 0u);
+        store_scales(a.tsc[11], b32, lane, emit_tfrag8_scaled(a.tdy_dens, b32, 1, 0, lane, dd, zero, P), 0u);
+    } else {
+        emit_tfrag(a.tdy_hd, b32, 1, 0, lane, dz, zero, P);
+        emit_tfrag(a.tdy_dens, b32, 1, 0, lane, dd, zero, P);
+    }
 
     WeightPipe pipe;
     pipe.src = pipe.base = (const char*)a.wbwd;
@@ -739,17 +826,17 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
 
     bf16x8 ga[HKS], gb[HKS], gw[WKS], none[1], dzv[1] = {dz}, ddv[1] = {dd};
     // heads^T: dX9 = Wh^T dz, masked by X9 > 0 -> dY9
-    bwd_layer<N, 0, WT, 1, 0, true, HW>(pipe, dzv, none, gw, kw9, a.mask[7], kwa, a.tdy[9], b32, P);
+    bwd_layer<N, 0, WT, 1, 0, true, HW>(pipe, dzv, none, gw, kw9, a.mask[7], kwa, a.tdy[9], a.tsc[9], b32, P);
     // [folded colour layer (columns of X7 only) ; density head]^T: dX7 = (W9a W8)^T dY9 + wd^T dd, masked by X7 > 0 -> dY7
-    bwd_layer<N, WS, HT, WKS, 1, true, HW, N::SAR>(pipe, gw, ddv, gb, kwa, a.mask[6], kwb, a.tdy[7], b32, P, x7, c0, c1);
-    bwd_layer<N, WS + 1 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[5], kwa, a.tdy[6], b32, P);
-    bwd_layer<N, WS + 2 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[4], kwb, a.tdy[5], b32, P);
-    bwd_layer<N, WS + 3 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[3], kwa, a.tdy[4], b32, P);
+    bwd_layer<N, WS, HT, WKS, 1, true, HW, N::SAR>(pipe, gw, ddv, gb, kwa, a.mask[6], kwb, a.tdy[7], a.tsc[7], b32, P, x7, c0, c1);
+    bwd_layer<N, WS + 1 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[5], kwa, a.tdy[6], a.tsc[6], b32, P);
+    bwd_layer<N, WS + 2 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[4], kwb, a.tdy[5], a.tsc[5], b32, P);
+    bwd_layer<N, WS + 3 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[3], kwa, a.tdy[4], a.tsc[4], b32, P);
     // density_net1.0^T (rows of X3 only; the encoding needs no gradient)
-    bwd_layer<N, WS + 4 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[2], kwb, a.tdy[3], b32, P);
-    bwd_layer<N, WS + 5 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[1], kwa, a.tdy[2], b32, P);
-    bwd_layer<N, WS + 6 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[0], kwb, a.tdy[1], b32, P);
-    bwd_layer<N, WS + 7 * HS, HT, HKS, 0, true, 0>(pipe, gb, none, ga, kwb, nullptr, nokw, a.tdy[0], b32, P);
+    bwd_layer<N, WS + 4 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[2], kwb, a.tdy[3], a.tsc[3], b32, P);
+    bwd_layer<N, WS + 5 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[1], kwa, a.tdy[2], a.tsc[2], b32, P);
+    bwd_layer<N, WS + 6 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[0], kwb, a.tdy[1], a.tsc[1], b32, P);
+    bwd_layer<N, WS + 7 * HS, HT, HKS, 0, true, 0>(pipe, gb, none, ga, kwb, nullptr, nokw, a.tdy[0], a.tsc[0], b32, P);
     static_assert(bwd_stage<N>(WS + 8 * HS).ks == 0 && bwd_stage<N>(WS + 8 * HS - 1).ks != 0, "stage table out of step");
 }
 
@@ -1031,6 +1118,211 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
             }
         }
         if (do_bias && a.gb[sa] != nullptr) {           // both lane halves: they hold different samples
+            const int nn = lt * 32 + c;
+            if (nn < a.A[sa].n_true) atomicAdd(&a.gb[sa][nn], accb[i]);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient from T-frag8 operands: the same streaming GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 x e4m3,
+// one E8M0 scale per operand lane).  A k-step is one block of 64 samples: per 32-feature tile two 1 KiB pieces (the
+// tile's two 32-sample blocks).  Operand lane map of the instruction (checked with exact data,
+// tools/microbench/mx_layout.hip): lane 32 kh + n holds row n; its bytes 0..15 and the bytes 0..15 of lane n's other
+// half form scale block 0 (scaled by the exponent lane n supplies), bytes 16..31 of both halves form scale block 1
+// (exponent supplied by lane 32 + n).  So lane 32 kh + n takes bytes 0..15 from the piece of sample block 2Q (the
+// 16 bytes the producing lane 32 kh + n wrote) and bytes 16..31 from the piece of block 2Q + 1, and supplies the
+// exponent of block 2Q + kh: a scale block is exactly one producer block.  Activations carry exponent 127.
+// Four waves own the whole [NT x KT] output; pieces and scale bytes of a k-step go HBM -> LDS by global_load_lds
+// into a ring (depth - 1 k-steps in flight behind a counted vmcnt), loads issued between the rows of MFMAs.
+typedef int v8i __attribute__((ext_vector_type(8)));
+struct Wgrad8Args {
+    WgradSeg A[2], B[2];           // dY side / X side segments (p = e4m3 data)
+    const unsigned char* Asc[2];   // scale bytes of the dY segments
+    WgradOut out[2][2];
+    float* gb[2];
+    int64_t nblk;                  // blocks of 64 samples = k-steps
+    int NT, KT, WN, WK;
+    int depth;
+};
+constexpr int kWg8MaxLoads = 10;   // data loads per wave and k-step (2 (NT + KT) pieces over 4 waves), + 1 for scale bytes
+
+template <int NTW, int KTW>
+__global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / a.WK, wk = wave % a.WK;
+    const int C = a.NT + a.KT;                      // tiles per sample block, dY tiles first
+    const int P = 2 * C;                            // data pieces per k-step: [block parity s][tile c]
+    const int G = (P + 3) / 4;                      // data loads per wave per k-step
+    const unsigned slot_bytes = (unsigned)(P + 1) * 1024;           // + 1 KiB: [segment][parity][256 B] scale bytes
+    LDS_AS char* ring = (LDS_AS char*)smem;
+    const int depth = a.depth;
+    LDS_AS char* scratch = ring + depth * slot_bytes;               // landing zone of padding loads, 1 KiB per wave
+    const int64_t q0 = blockIdx.x, qstride = gridDim.x;
+    const int64_t n = q0 < a.nblk ? (a.nblk - q0 + qstride - 1) / qstride : 0;
+
+    f32x16 acc[NTW][KTW];
+    float accb[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        accb[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    const bool do_bias = (a.gb[0] != nullptr || a.gb[1] != nullptr) && wk == 0;
+
+    // per-load source description, fixed for the sweep (wave-uniform): address = base + k-step * stride
+    const char* ld_base[kWg8MaxLoads];
+    int64_t ld_stride[kWg8MaxLoads];
+    unsigned ld_dst[kWg8MaxLoads];
+    bool ld_real[kWg8MaxLoads];
+#pragma unroll
+    for (int g = 0; g < kWg8MaxLoads; ++g) {
+        const int p = g * 4 + wave;
+        ld_real[g] = g < G && p < P;
+        const int sp = p >= C ? 1 : 0, c = p - sp * C;
+        const bool xside = c >= a.NT;
+        const int t = xside ? c - a.NT : c;
+        const WgradSeg s0 = xside ? a.B[0] : a.A[0], s1 = xside ? a.B[1] : a.A[1];
+        const bool second = t >= s0.tiles;
+        const WgradSeg sg = second ? s1 : s0;
+        const int lt = second ? t - s0.tiles : t;
+        ld_base[g] = ld_real[g] ? (const char*)sg.p + ((int64_t)sp * sg.tiles + lt) * 1024 : (const char*)a.A[0].p;
+        ld_stride[g] = ld_real[g] ? (int64_t)2 * sg.tiles * 1024 : 0;
+        ld_dst[g] = (unsigned)p * 1024;
+    }
+    // scale bytes: wave w fetches the 256 B of (segment w >> 1, block parity w & 1)
+    const bool sc_real = a.A[wave >> 1].tiles > 0 && a.Asc[wave >> 1] != nullptr;
+    const char* sc_base = sc_real ? (const char*)a.Asc[wave >> 1] + (wave & 1) * 256 : (const char*)a.A[0].p;
+    const unsigned sc_dst = (unsigned)P * 1024 + wave * 256;
+
+    int fill = 0, drain = 0;
+    int64_t is_q = 0;
+    LDS_AS char* is_slot = ring;
+    bool is_live = false;
+    auto begin_issue = [&](int64_t i) {
+        is_q = q0 + i * qstride;
+        is_slot = ring + (unsigned)fill * slot_bytes;
+        fill = fill + 1 == depth ? 0 : fill + 1;
+        is_live = i < n;
+    };
+    auto issue_load = [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if (g < G) {
+            const bool real = is_live && ld_real[g];
+            const char* src = real ? ld_base[g] + is_q * ld_stride[g] : (const char*)a.A[0].p;
+            LDS_AS char* dst = real ? is_slot + ld_dst[g] : scratch + wave * 1024;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + lane * 16), (LDS_AS void*)dst, 16, 0, 0);
+        }
+    };
+    auto issue_scales = [&]() {
+        const bool real = is_live && sc_real;
+        const char* src = real ? sc_base + is_q * 512 : (const char*)a.A[0].p;
+        LDS_AS char* dst = real ? is_slot + sc_dst : scratch + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + lane * 4), (LDS_AS void*)dst, 4, 0, 0);
+    };
+    auto issue_all = [&](int64_t i) {
+        begin_issue(i);
+        issue_scales();
+        static_for<0, kWg8MaxLoads>([&](auto gc) __attribute__((always_inline)) { issue_load(gc); });
+    };
+    const int GL = G + 1;                           // vector-memory operations per wave per k-step
+
+    // which segment / local tile each owned output row is, fixed for the sweep
+    int a_seg[NTW], a_lt[NTW], a_c[NTW];
+#pragma unroll
+    for (int ii = 0; ii < NTW; ++ii) {
+        int nt = wn * NTW + ii;
+        if (nt >= a.NT) nt = 0;
+        a_c[ii] = nt;
+        a_seg[ii] = nt >= a.A[0].tiles ? 1 : 0;
+        a_lt[ii] = a_seg[ii] ? nt - a.A[0].tiles : nt;
+    }
+    const int n_lo = lane & 31, kh = lane >> 5;
+
+    for (int i = 0; i < depth - 1; ++i) issue_all(i);
+    for (int64_t i = 0; i < n; ++i) {
+        wait_vmcnt((depth - 2) * GL);               // this wave's part of k-step i has landed
+        __builtin_amdgcn_s_barrier();               // everyone's has; everyone is done reading k-step i - 1's slot
+        LDS_AS const char* slot = ring + (unsigned)drain * slot_bytes;
+        drain = drain + 1 == depth ? 0 : drain + 1;
+        v8i A[NTW], B[KTW];
+        int SA[NTW];
+        float sc0[NTW], sc1[NTW];
+#pragma unroll
+        for (int ii = 0; ii < NTW; ++ii) {
+            const u32x4 lo = *(LDS_AS const u32x4*)(slot + a_c[ii] * 1024 + lane * 16);
+            const u32x4 hi = *(LDS_AS const u32x4*)(slot + (C + a_c[ii]) * 1024 + lane * 16);
+            A[ii] = (v8i){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            LDS_AS const unsigned char* sp = (LDS_AS const unsigned char*)(slot + P * 1024 + a_seg[ii] * 512 + n_lo * 8 + a_lt[ii]);
+            const unsigned e0 = sp[0], e1 = sp[256];                     // exponents of blocks 2Q and 2Q + 1
+            SA[ii] = (int)(kh ? e1 : e0);
+            sc0[ii] = __uint_as_float(e0 << 23);
+            sc1[ii] = __uint_as_float(e1 << 23);
+        }
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) {
+            int kt = wk * KTW + j;
+            if (kt >= a.KT) kt = 0;
+            const u32x4 lo = *(LDS_AS const u32x4*)(slot + (a.NT + kt) * 1024 + lane * 16);
+            const u32x4 hi = *(LDS_AS const u32x4*)(slot + (C + a.NT + kt) * 1024 + lane * 16);
+            B[j] = (v8i){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+        begin_issue(i + depth - 1);
+        issue_scales();
+        static_for<0, NTW>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int ii = decltype(ic)::value;
+            static_for<0, kWg8MaxLoads>([&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value;
+                if constexpr ((g * NTW) / kWg8MaxLoads == ii) issue_load(gc);
+            });
+#pragma unroll
+            for (int j = 0; j < KTW; ++j)
+                acc[ii][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[ii], B[j], acc[ii][j], 0, 0, 0, SA[ii], 0, 127);
+            if (do_bias) {          // column sums of dY (bias gradient) on the vector ALU, by the waves that own them
+                typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x2_ l0 = __builtin_amdgcn_cvt_pk_f32_fp8(A[ii][q], false), h0 = __builtin_amdgcn_cvt_pk_f32_fp8(A[ii][q], true);
+                    const f32x2_ l1 = __builtin_amdgcn_cvt_pk_f32_fp8(A[ii][4 + q], false), h1 = __builtin_amdgcn_cvt_pk_f32_fp8(A[ii][4 + q], true);
+                    s0 += (l0[0] + l0[1]) + (h0[0] + h0[1]);
+                    s1 += (l1[0] + l1[1]) + (h1[0] + h1[1]);
+                }
+                accb[ii] += s0 * sc0[ii] + s1 * sc1[ii];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS write may outlive the workgroup
+
+    const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int nt = wn * NTW + i;
+        if (nt >= a.NT) continue;
+        const int sa = nt >= a.A[0].tiles, lt = sa ? nt - a.A[0].tiles : nt;
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) {
+            const int kt = wk * KTW + j;
+            if (kt >= a.KT) continue;
+            const int sb = kt >= a.B[0].tiles, lk = sb ? kt - a.B[0].tiles : kt;
+            const WgradOut o = a.out[sa][sb];
+            const int k = lk * 32 + c;
+            if (o.G == nullptr || k >= a.B[sb].n_true) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = lt * 32 + acc_row(r, h);
+                if (nn < a.A[sa].n_true) atomicAdd(&o.G[(int64_t)nn * o.ld + o.col0 + k], acc[i][j][r]);
+            }
+        }
+        if (do_bias && a.gb[sa] != nullptr) {
             const int nn = lt * 32 + c;
             if (nn < a.A[sa].n_true) atomicAdd(&a.gb[sa][nn], accb[i]);
         }
@@ -1402,12 +1694,13 @@ extern "C" int nerf_view_frag(const float* dirs, int64_t n_rays, int min_deg, in
 
 extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* consts, const void* enc_frag,
                             const void* view_frag, int64_t n_samples, int ray_div, int64_t n_rays,
-                            void* const* acts /* 22 (SAR: 23) pointers or NULL */, float* raw_density,
+                            void* const* acts /* 22 (SAR: 23) pointers or NULL */, int tfrag_fmt, float* raw_density,
                             float* raw_rgb, float* raw_angle, float* ln_stats, void* stream) {
     if (n_samples == 0) return NERF_OK;
     HostDims d;
     NERF_REQUIRE(make_dims(dims, &d) && wfwd && consts && enc_frag && view_frag && raw_density && raw_rgb);
     NERF_REQUIRE(n_samples > 0 && ray_div > 0 && n_rays > 0);
+    NERF_REQUIRE(tfrag_fmt == NERF_TFRAG_BF16 || tfrag_fmt == NERF_TFRAG_E4M3);
     if (d.sar) NERF_REQUIRE(raw_angle != nullptr);
     MlpFwdArgs a;
     a.wfwd = (const bf16x8*)wfwd;
@@ -1432,9 +1725,11 @@ extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const f
     a.raw_rgb = raw_rgb;
     a.raw_angle = raw_angle;
     a.ln_stats = ln_stats;
-#define X(ht_, wt_, dks_, vks_, sar_)                                                          \
-    if (d.HT == ht_ && d.WT == wt_ && d.DKS == dks_ && d.VKS == vks_ && (d.sar != 0) == sar_)  \
-        return launch_fwd<Net<ht_, wt_, dks_, vks_, sar_>>(a, nerf_stream(stream));
+#define X(ht_, wt_, dks_, vks_, sar_)                                                             \
+    if (d.HT == ht_ && d.WT == wt_ && d.DKS == dks_ && d.VKS == vks_ && (d.sar != 0) == sar_)     \
+        return (acts && tfrag_fmt == NERF_TFRAG_E4M3)                                             \
+                   ? launch_fwd<Net<ht_, wt_, dks_, vks_, sar_, true>>(a, nerf_stream(stream))    \
+                   : launch_fwd<Net<ht_, wt_, dks_, vks_, sar_, false>>(a, nerf_stream(stream));
     NERF_NET_LIST(X)
 #undef X
     return NERF_ERR_SIZE;
@@ -1453,8 +1748,9 @@ extern "C" int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, const f
                             const float* g_density, const float* g_rgb, const float* g_angle, const float* raw_density,
                             const float* raw_rgb, const float* raw_angle, const float* ln_stats,
                             void* const* acts /* as nerf_mlp_fwd */,
-                            void* const* dys /* 12 T-frag buffers: dY0..dY7, unused, dY9, colour head tile, density head tile */,
-                            void* stream) {
+                            void* const* dys /* 12 T-frag buffers: dY0..dY7, unused, dY9, colour head tile, density head
+                                                tile; e4m3 form: 12 more, their scale bytes */,
+                            int tfrag_fmt, void* stream) {
     if (n_samples == 0) return NERF_OK;
     HostDims d;
     NERF_REQUIRE(make_dims(dims, &d) && wbwd && g_density && g_rgb && raw_rgb && acts && dys && n_samples > 0);
@@ -1473,11 +1769,18 @@ extern "C" int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, const f
         a.tdy[i] = (bf16x8*)dys[i];
     }
     NERF_REQUIRE(dys[10] && dys[11]);
+    NERF_REQUIRE(tfrag_fmt == NERF_TFRAG_BF16 || tfrag_fmt == NERF_TFRAG_E4M3);
     a.tdy_hd = (bf16x8*)dys[10];
     a.tdy_dens = (bf16x8*)dys[11];
+    for (int i = 0; i < 12; ++i) {
+        a.tsc[i] = tfrag_fmt == NERF_TFRAG_E4M3 ? dys[12 + i] : nullptr;
+        if (tfrag_fmt == NERF_TFRAG_E4M3) NERF_REQUIRE(a.tsc[i] != nullptr || i == 8);
+    }
 #define X(ht_, wt_, dks_, vks_, sar_)                                                            \
     if (d.HT == ht_ && d.WT == wt_ && d.DKS == dks_ && d.VKS == vks_ && (d.sar != 0) == sar_)     \
-        return launch_bwd<Net<ht_, wt_, dks_, vks_, sar_>>(a, nerf_stream(stream));
+        return tfrag_fmt == NERF_TFRAG_E4M3                                                       \
+                   ? launch_bwd<Net<ht_, wt_, dks_, vks_, sar_, true>>(a, nerf_stream(stream))    \
+                   : launch_bwd<Net<ht_, wt_, dks_, vks_, sar_, false>>(a, nerf_stream(stream));
     NERF_NET_LIST(X)
 #undef X
     return NERF_ERR_SIZE;
@@ -1530,16 +1833,87 @@ static int launch_wgrad(const WgradArgs& a, unsigned grid, size_t lds, hipStream
     return nerf_launch_status();
 }
 
+
+template <int NTW, int KTW>
+static int launch_wgrad8(const Wgrad8Args& a, unsigned grid, size_t lds, hipStream_t st) {
+    static std::atomic<unsigned long long> done{0};
+    if (!allow_dynamic_lds((const void*)mlp_wgrad8_kernel<NTW, KTW>, kWgradLds, done)) return NERF_ERR_LAUNCH;
+    hipLaunchKernelGGL((mlp_wgrad8_kernel<NTW, KTW>), dim3(grid), dim3(256), lds, st, a);
+    return nerf_launch_status();
+}
+
+// Split NT x KT output tiles over 4 waves (WN x WK) for the e4m3 kernel: the instantiation with the fewest tiles.
+static bool wgrad8_config(int NT, int KT, int* WN, int* WK, int* tn, int* tk) {
+    static const int kSplit[3][2] = {{2, 2}, {4, 1}, {1, 4}};
+    static const int kTmpl[9][2] = {{1, 1}, {1, 2}, {2, 2}, {2, 3}, {3, 3}, {4, 4}, {4, 5}, {5, 3}, {5, 4}};
+    int best = 1 << 30;
+    *tn = *tk = 0;
+    for (const auto& sp : kSplit) {
+        const int ntw = (NT + sp[0] - 1) / sp[0], ktw = (KT + sp[1] - 1) / sp[1];
+        for (const auto& t : kTmpl)
+            if (t[0] >= ntw && t[1] >= ktw && t[0] * t[1] < best) {
+                best = t[0] * t[1]; *tn = t[0]; *tk = t[1]; *WN = sp[0]; *WK = sp[1];
+            }
+    }
+    return *tn != 0;
+}
+
+static int wgrad8_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint, hipStream_t st) {
+    Wgrad8Args a;
+    a.NT = a.KT = 0;
+    for (int i = 0; i < 2; ++i) {
+        const int nf = d->dy_feat[i], kf = d->x_feat[i];
+        a.A[i] = {(const bf16x8*)d->dy[i], nf / 32, d->dy_true[i]};
+        a.B[i] = {(const bf16x8*)d->x[i], kf / 32, d->x_true[i]};
+        a.Asc[i] = (const unsigned char*)d->dy_scale[i];
+        if (nf > 0 && a.Asc[i] == nullptr) return NERF_ERR_ARG;
+        if (nf / 32 > 8) return NERF_ERR_SIZE;              // 8 scale bytes per feature row and sample block
+        a.gb[i] = nf ? d->gb[i] : nullptr;
+        a.NT += nf / 32;
+        a.KT += kf / 32;
+        for (int j = 0; j < 2; ++j) a.out[i][j] = {d->G[i][j], d->ld[i][j], d->col0[i][j]};
+    }
+    a.nblk = ((n_samples + 255) / 256) * 4;
+    int tn = 0, tk = 0;
+    if (!wgrad8_config(a.NT, a.KT, &a.WN, &a.WK, &tn, &tk)) return NERF_ERR_SIZE;
+    const int pieces = 2 * (a.NT + a.KT), loads = (pieces + 3) / 4;
+    if (loads > kWg8MaxLoads) return NERF_ERR_SIZE;
+    a.depth = (kWgradLds / 1024 - 4) / (pieces + 1);
+    if (a.depth > 6) a.depth = 6;
+    if ((a.depth - 2) * (loads + 1) > 63) a.depth = 63 / (loads + 1) + 2;
+    if (a.depth < 3) return NERF_ERR_SIZE;
+    unsigned grid = grid_hint > 0 ? (unsigned)grid_hint : 256u;
+    if ((int64_t)grid > a.nblk) grid = (unsigned)a.nblk;
+    const size_t lds = (size_t)(a.depth * (pieces + 1) + 4) * 1024;
+#define NERF_W8(n_, k_) if (tn == n_ && tk == k_) return launch_wgrad8<n_, k_>(a, grid, lds, st);
+    NERF_W8(1, 1) NERF_W8(1, 2) NERF_W8(2, 2) NERF_W8(2, 3) NERF_W8(3, 3) NERF_W8(4, 4) NERF_W8(4, 5) NERF_W8(5, 3) NERF_W8(5, 4)
+#undef NERF_W8
+    return NERF_ERR_SIZE;
+}
+
+// Which mlp_wgrad8_kernel<tn, tk> instantiation an e4m3 launch with these total padded feature counts uses.
+extern "C" int nerf_mlp_wgrad8_config(int n_feat, int k_feat, int* tn, int* tk) {
+    int wn, wk;
+    NERF_REQUIRE(tn && tk && n_feat > 0 && k_feat > 0 && n_feat % 32 == 0 && k_feat % 32 == 0);
+    return wgrad8_config(n_feat / 32, k_feat / 32, &wn, &wk, tn, tk) ? NERF_OK : NERF_ERR_SIZE;
+}
+
 // dW blocks for up to two dY buffers x two X buffers in one pass over the samples (each operand byte read once).
 extern "C" int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint, void* stream) {
     if (n_samples == 0) return NERF_OK;
     NERF_REQUIRE(d && n_samples > 0);
-    WgradArgs a;
-    a.NT = a.KT = 0;
+    NERF_REQUIRE(d->tfrag_fmt == NERF_TFRAG_BF16 || d->tfrag_fmt == NERF_TFRAG_E4M3);
     for (int i = 0; i < 2; ++i) {
         const int nf = d->dy_feat[i], kf = d->x_feat[i];
         NERF_REQUIRE(nf >= 0 && kf >= 0 && nf % 32 == 0 && kf % 32 == 0 && (i == 1 || (nf > 0 && kf > 0)));
         NERF_REQUIRE((nf == 0 || d->dy[i]) && (kf == 0 || d->x[i]) && d->dy_true[i] <= nf && d->x_true[i] <= kf);
+    }
+    NERF_REQUIRE(d->G[0][0] != nullptr);
+    if (d->tfrag_fmt == NERF_TFRAG_E4M3) return wgrad8_multi(d, n_samples, grid_hint, nerf_stream(stream));
+    WgradArgs a;
+    a.NT = a.KT = 0;
+    for (int i = 0; i < 2; ++i) {
+        const int nf = d->dy_feat[i], kf = d->x_feat[i];
         a.A[i] = {(const bf16x8*)d->dy[i], nf / 32, d->dy_true[i]};
         a.B[i] = {(const bf16x8*)d->x[i], kf / 32, d->x_true[i]};
         a.gb[i] = nf ? d->gb[i] : nullptr;

@@ -18,24 +18,30 @@ _lib.register('nerf_mlp_pack', c_int, [POINTER(MlpDims), POINTER(c_void_p), _P, 
 _lib.register('nerf_encode_frag', c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P, _P])
 _lib.register('nerf_view_frag', c_int, [_P, c_int64, c_int, c_int, _P, _P])
 _lib.register('nerf_mlp_fwd', c_int, [POINTER(MlpDims), _P, _P, _P, _P, c_int64, c_int, c_int64, POINTER(c_void_p),
-                                      _P, _P, _P, _P, _P])
+                                      c_int, _P, _P, _P, _P, _P])
 
 _lib.register('nerf_mlp_bwd', c_int, [POINTER(MlpDims), _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, POINTER(c_void_p),
-                                      POINTER(c_void_p), _P])
+                                      POINTER(c_void_p), c_int, _P])
 class WgradDesc(ctypes.Structure):
     """nerf_wgrad_desc of include/nerf_amd.h."""
     _fields_ = [('dy', c_void_p * 2), ('dy_feat', c_int * 2), ('dy_true', c_int * 2),
                 ('x', c_void_p * 2), ('x_feat', c_int * 2), ('x_true', c_int * 2),
-                ('G', (c_void_p * 2) * 2), ('ld', (c_int * 2) * 2), ('col0', (c_int * 2) * 2), ('gb', c_void_p * 2)]
+                ('G', (c_void_p * 2) * 2), ('ld', (c_int * 2) * 2), ('col0', (c_int * 2) * 2), ('gb', c_void_p * 2),
+                ('tfrag_fmt', c_int), ('dy_scale', c_void_p * 2)]
 
 
 _lib.register('nerf_mlp_wgrad_multi', c_int, [POINTER(WgradDesc), c_int64, c_int, _P])
 _lib.register('nerf_mlp_wgrad_config', c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)])
+_lib.register('nerf_mlp_wgrad8_config', c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)])
 _lib.register('nerf_mlp_wgrad', c_int, [_P, c_int, _P, c_int, c_int64, _P, c_int, c_int, c_int, c_int, _P, c_int, _P])
 
 STREAMED = (['density_net0.%d' % i for i in (0, 2, 4, 6)] + ['density_net1.%d' % i for i in (0, 2, 4, 6)]
             + ['rgb_net0.0', 'rgb_net1.0'])
 RAY_SHAPES = {'cone': 0, 'cylinder': 1}
+# Storage format of the weight-gradient operands the chain kernels save (NERF_TFRAG_* of include/nerf_amd.h).
+# `config.wgrad_operands` ('bf16' or 'e4m3') selects it per model; this is the default.
+TFRAG_FORMATS = {'bf16': 0, 'e4m3': 1}
+DEFAULT_WGRAD_OPERANDS = 'e4m3'
 
 
 def _raw(t):
@@ -56,6 +62,7 @@ class Packed:
         D = 6 * (cfg.max_deg - cfg.min_deg)
         V = 3 + 6 * (cfg.viewdirs_max_deg - cfg.viewdirs_min_deg)
         self.dims = MlpDims(D, V, H, W, int(self.sar))
+        self.fmt = TFRAG_FORMATS[getattr(cfg, 'wgrad_operands', None) or DEFAULT_WGRAD_OPERANDS]
         self.H, self.W, self.D, self.V = H, W, D, V
         self.HT, self.WT = (H + 31) // 32, (W + 31) // 32
         self.DKS, self.VKS = (D + 15) // 16, (V + 15) // 16
@@ -117,7 +124,7 @@ class Packed:
         self.wgrad_flops = 2.0 * macs_fwd
         self.DT, self.VT = (self.DKS + 1) // 2, (self.VKS + 1) // 2
         # bf16 operand bytes per sample that the weight-gradient launches read (see _wgrad_plan)
-        self.wgrad_bytes = 2.0 * sum(sum(s[1] for s in dys) + sum(s[1] for s in xs) for dys, xs, _ in _wgrad_plan(self))
+        self.wgrad_bytes = sum(_wgrad_launch_bytes(self, dys, xs) for dys, xs, _ in _wgrad_plan(self))
 
 
 def _wgrad_plan(pk):
@@ -147,6 +154,14 @@ def _wgrad_plan(pk):
     return plan
 
 
+def _wgrad_launch_bytes(pk, dsegs, xsegs):
+    """Operand bytes per sample that one weight-gradient launch reads."""
+    feats = sum(s[1] for s in dsegs) + sum(s[1] for s in xsegs)
+    if pk.fmt == 0:
+        return 2.0 * feats
+    return 1.0 * feats + 8.0 * len(dsegs)           # e4m3 + 256 scale bytes per 32-sample block and dY segment
+
+
 def _param_versions(model):
     # torch bumps a tensor's version on every in-place write (optimizer steps, load_state_dict, .copy_), and
     # data_ptr changes when a parameter is replaced: together they identify the weights the streams were packed from
@@ -156,7 +171,7 @@ def _param_versions(model):
 def packed_for(model, need_bwd=True):
     """The packed bf16 streams of `model`, re-packed whenever a parameter has been written since the last packing."""
     pk = getattr(model, '_packed', None)
-    versions = _param_versions(model)
+    versions = _param_versions(model) + (getattr(model.config, 'wgrad_operands', None),)
     if pk is None or pk.versions != versions or (need_bwd and pk.wbwd is None):
         pk = Packed(model, need_bwd)
         pk.versions = versions
@@ -192,17 +207,22 @@ def view_frag(dirs, min_deg, max_deg):
 def act_block_bytes(pk):
     """Bytes per block of 64 samples of each buffer the forward chain saves (index as in `acts`; None = unused)."""
     tiles = [pk.HT] * 9 + [pk.WT]
-    per = [t * 4096 if i != 8 else None for i, t in enumerate(tiles)]
+    piece = 4096 >> pk.fmt                          # transposed fragments: bf16 or e4m3
+    per = [t * piece if i != 8 else None for i, t in enumerate(tiles)]
     per += [2 * ((t + 1) // 2) * 256 if i != 8 else None for i, t in enumerate(tiles)]
-    per += [pk.DT * 4096, pk.VT * 4096]
+    per += [pk.DT * piece, pk.VT * piece]
     if pk.sar:
         per.append(32 * pk.HT * 128)
     return per
 
 
 def dy_block_bytes(pk):
-    """Bytes per block of 64 samples of each dY buffer of the backward chain (None = unused)."""
-    return [t * 4096 if i != 8 else None for i, t in enumerate([pk.HT] * 9 + [pk.WT, 1, 1])]
+    """Bytes per block of 64 samples of each dY buffer of the backward chain (None = unused); in the e4m3 format 12
+    more entries: the scale bytes of each (8 bytes per feature row and 32-sample block)."""
+    per = [t * (4096 >> pk.fmt) if i != 8 else None for i, t in enumerate([pk.HT] * 9 + [pk.WT, 1, 1])]
+    if pk.fmt:
+        per += [512 if i != 8 else None for i in range(12)]
+    return per
 
 
 def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False, acts=None, raw=None):
@@ -220,19 +240,13 @@ def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False, acts=None
     elif save:
         # 0..9 X0..X7, X9 as T-frags (8 unused: rgb_net0's output is never formed), 10..19 their ReLU sign words,
         # 20 enc, 21 view T-frags
-        tiles = [pk.HT] * 9 + [pk.WT]
-        acts = [torch.empty(nblk * t * 4096, dtype=torch.uint8, device=dev) if i != 8 else None for i, t in enumerate(tiles)]
-        acts += [torch.empty(nblk * 2 * ((t + 1) // 2) * 256, dtype=torch.uint8, device=dev) if i != 8 else None
-                 for i, t in enumerate(tiles)]
-        acts += [torch.empty(nblk * pk.DT * 4096, dtype=torch.uint8, device=dev),
-                 torch.empty(nblk * pk.VT * 4096, dtype=torch.uint8, device=dev)]
-        if pk.sar:       # 22: the trunk output once more in frag order, for the LayerNorm backward
-            acts.append(torch.empty(nblk * 32 * pk.HT * 128, dtype=torch.uint8, device=dev))
+        acts = [torch.empty(nblk * b, dtype=torch.uint8, device=dev) if b is not None else None
+                for b in act_block_bytes(pk)]        # (22, SAR only: the trunk output once more in frag order)
         arr = (c_void_p * len(acts))(*[a.data_ptr() if a is not None else None for a in acts])
     saved = sum(a.numel() for a in acts if a is not None) if acts is not None else 0   # bytes the launch writes for the backward pass
     with profiling.timed('mlp_fwd_kernel', flops=pk.fwd_flops * n_samples, bytes_=float(saved)):
         check(lib().nerf_mlp_fwd(ctypes.byref(pk.dims), _raw(pk.wfwd), ptr(pk.consts), _raw(enc), _raw(view),
-                                 n_samples, ray_div, n_rays, arr, ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
+                                 n_samples, ray_div, n_rays, arr, pk.fmt, ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
                                  ptr(ln_stats), stream()))
     return raw_density, raw_rgb, raw_angle, acts, ln_stats
 
@@ -244,18 +258,17 @@ def mlp_backward(pk, acts, n_samples, g_density, g_rgb, raw_rgb, g_angle=None, r
     `dys` may be supplied (dy_block_bytes layout); `n_real` is the sample count the work is accounted for."""
     dev = g_density.device
     nblk = n_blocks(n_samples)
-    tiles = [pk.HT] * 9 + [pk.WT, 1, 1]
     if dys is None:
-        dys = [torch.empty(nblk * t * 4096, dtype=torch.uint8, device=dev) if i != 8 else None for i, t in enumerate(tiles)]
+        dys = [torch.empty(nblk * b, dtype=torch.uint8, device=dev) if b is not None else None for b in dy_block_bytes(pk)]
     a_arr = (c_void_p * len(acts))(*[a.data_ptr() if a is not None else None for a in acts])
-    d_arr = (c_void_p * 12)(*[d.data_ptr() if d is not None else None for d in dys])
+    d_arr = (c_void_p * len(dys))(*[d.data_ptr() if d is not None else None for d in dys])
     g_density, g_rgb = f32c(g_density).reshape(-1), f32c(g_rgb).reshape(-1, 3)
     if pk.sar:
         g_angle = f32c(g_angle).reshape(-1, 2)
     with profiling.timed('mlp_bwd_kernel', flops=pk.bwd_dx_flops * (n_real or n_samples), bytes_=float(sum(d.numel() for d in dys if d is not None))):
         check(lib().nerf_mlp_bwd(ctypes.byref(pk.dims), _raw(pk.wbwd), ptr(pk.consts), n_samples, ptr(g_density),
                                  ptr(g_rgb), ptr(g_angle), ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
-                                 ptr(ln_stats), a_arr, d_arr, stream()))
+                                 ptr(ln_stats), a_arr, d_arr, pk.fmt, stream()))
     return dys
 
 
@@ -263,9 +276,13 @@ _WGRAD_KERNEL = {}
 WGRAD_GRID = 0          # workgroups per weight-gradient launch; 0 = one per compute unit
 
 
-def wgrad_kernel_name(n_feat, k_feat):
+def wgrad_kernel_name(n_feat, k_feat, fmt=0):
     """Symbol of the kernel instantiation that handles these feature counts."""
-    key = (n_feat, k_feat)
+    key = (n_feat, k_feat, fmt)
+    if key not in _WGRAD_KERNEL and fmt:
+        tn, tk = c_int(), c_int()
+        check(lib().nerf_mlp_wgrad8_config(n_feat, k_feat, ctypes.byref(tn), ctypes.byref(tk)))
+        _WGRAD_KERNEL[key] = 'mlp_wgrad8_kernel<%d, %d>' % (tn.value, tk.value)
     if key not in _WGRAD_KERNEL:
         nw, tn, tk, gt = c_int(), c_int(), c_int(), c_int()
         check(lib().nerf_mlp_wgrad_config(n_feat, k_feat, ctypes.byref(nw), ctypes.byref(tn), ctypes.byref(tk),
@@ -309,9 +326,12 @@ def mlp_weight_grads(pk, acts, dys, n_samples, grads):
 def _wgrad_launches(pk, acts, dys, n_samples, grads):
     for dsegs, xsegs, blocks in _wgrad_plan(pk):
         d = WgradDesc()
+        d.tfrag_fmt = pk.fmt
         flops = 0.0
         for i, (di, nf, nt, name) in enumerate(dsegs):
             d.dy[i], d.dy_feat[i], d.dy_true[i] = dys[di].data_ptr(), nf, nt
+            if pk.fmt:
+                d.dy_scale[i] = dys[12 + di].data_ptr()
             d.gb[i] = grads[name + '.bias'].data_ptr()
         for j, (xs, kf, kt) in enumerate(xsegs):
             x = acts[20] if xs == 'enc' else acts[21] if xs == 'view' else acts[xs[1]]
@@ -326,7 +346,8 @@ def _wgrad_launches(pk, acts, dys, n_samples, grads):
                         flops += 2.0 * pk.H * pk.H * n_samples
         nf_all, kf_all = sum(s[1] for s in dsegs), sum(s[1] for s in xsegs)
         # algorithmic work of the launch: every operand byte once, 2 FLOP per true multiply-add
-        with profiling.timed(wgrad_kernel_name(nf_all, kf_all), flops=flops, bytes_=2.0 * (nf_all + kf_all) * n_samples):
+        with profiling.timed(wgrad_kernel_name(nf_all, kf_all, pk.fmt), flops=flops,
+                             bytes_=_wgrad_launch_bytes(pk, dsegs, xsegs) * n_samples):
             check(lib().nerf_mlp_wgrad_multi(ctypes.byref(d), n_samples, WGRAD_GRID, stream()))
 
 
