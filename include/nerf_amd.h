@@ -329,8 +329,9 @@ int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_h
  * counts uses (gt = compile-time loads per wave and k-step, 0 = run-time count), so a profiler can label launches
  * by kernel symbol.  (No reference counterpart: measurement support.) */
 int nerf_mlp_wgrad_config(int n_feat, int k_feat, int* nw, int* tn, int* tk, int* gt);
-/* The same for NERF_TFRAG_E4M3 launches: mlp_wgrad8_kernel<tn, tk>. */
-int nerf_mlp_wgrad8_config(int n_feat, int k_feat, int* tn, int* tk);
+/* The same for NERF_TFRAG_E4M3 launches: mlp_wgrad8_kernel<tn, tk, gs> (gs = compile-time data loads per wave and
+ * k-step, 0 = run-time count). */
+int nerf_mlp_wgrad8_config(int n_feat, int k_feat, int* tn, int* tk, int* gs);
 
 #ifdef __cplusplus
 }

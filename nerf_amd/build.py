@@ -25,6 +25,7 @@ UNITS = {
     'composite.hip': ['-ffp-contract=off'],
     'gemm_f32.hip': [],
     'mlp_bf16.hip': [],      # default contraction: MFMA chain, fp32 epilogues
+    'wgrad8.hip': [],
 }
 
 

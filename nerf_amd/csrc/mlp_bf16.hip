@@ -37,19 +37,8 @@
 #include <atomic>
 
 #include "common.h"
+#include "mlp_frag.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define GLOBAL_AS __attribute__((address_space(1)))
-#define LDS_AS __attribute__((address_space(3)))
-
-// feature index inside a 32-row tile of accumulator register r for lane half h
-__device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-// feature index inside a 16-feature k-step of fragment element j for lane half h
-__device__ __host__ __forceinline__ constexpr int frag_feat(int j, int h) { return 8 * (j >> 2) + 4 * h + (j & 3); }
 
 // max(x, 0) as one v_med3_f32 (no NaN canonicalisation pass in front of it)
 __device__ __forceinline__ float relu_f(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
@@ -61,10 +50,6 @@ __device__ __forceinline__ bf16x8 relu_bf16(bf16x8 x) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // Eight fp32 accumulator values -> one bf16 piece, two per v_cvt_pk_bf16_f32 (round to nearest even).
 __device__ __forceinline__ bf16x8 pack_bf16x8(const f32x16& v, int first) {
@@ -128,8 +113,8 @@ __device__ __forceinline__ void emit_tfrag(bf16x8* dst, int64_t b32, int NT, int
 //          sample (r & 3) + 8 (r >> 2) + 4 hh of the block -- the 16 accumulator registers of the transposing MFMAs as
 //          they stand, one 1 KiB piece per (block, tile);
 //   scales [block of 32 samples][32 features n][8 bytes] (gradient buffers only): byte t is the E8M0 exponent e of
-//          (block, tile t, feature n): stored value = true value * 2^(127 - e), e chosen so that the block's largest
-//          magnitude lands in [128, 256).  One exponent per (feature, 32 samples) is the MX block of
+//          (block, tile t, feature n): stored value = true value * 2^(127 - e), e >= 1 chosen so that the block's
+//          largest magnitude lands in [128, 256).  One exponent per (feature, 32 samples) is the MX block of
 //          v_mfma_scale_f32_32x32x64_f8f6f4 along its reduction axis.  Activations are stored unscaled (e = 127).
 __device__ __forceinline__ u32x4 pack_fp8x16(const f32x16& t) {
     u32x4 o;
@@ -164,11 +149,18 @@ __device__ __forceinline__ unsigned emit_tfrag8_scaled(void* dst, int64_t b32, i
     for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(t[r]));
     amax = fmaxf(amax, __shfl_xor(amax, 32));                       // the other 16 samples of the block
     const int field = (int)(__float_as_uint(amax) >> 23);            // biased exponent of the largest magnitude
-    const unsigned e = (unsigned)(field > 7 ? field - 7 : 0);
-    const float inv = __uint_as_float((254u - e) << 23);             // 2^(127 - e): largest magnitude -> [128, 256)
+    const unsigned e = (unsigned)(field > 8 ? field - 7 : 1);        // largest magnitude / 2^(e - 127) in [128, 256)
+    const float scale = __uint_as_float(e << 23);                    // 2^(e - 127); the conversion divides by it
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    u32x4 o;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] *= inv;
-    __builtin_nontemporal_store(pack_fp8x16(t), (u32x4*)dst + (b32 * NT + nt) * 64 + lane);
+    for (int q = 0; q < 4; ++q) {
+        s16x2 w = {0, 0};
+        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, t[4 * q], t[4 * q + 1], scale, false);
+        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, t[4 * q + 2], t[4 * q + 3], scale, true);
+        o[q] = __builtin_bit_cast(unsigned, w);
+    }
+    __builtin_nontemporal_store(o, (u32x4*)dst + (b32 * NT + nt) * 64 + lane);
     return e;
 }
 // the exponents of up to 8 tiles of one block, by the lower lane half (both halves hold the same values)
@@ -329,16 +321,6 @@ constexpr int bwd_younger(int s) {
     return y;
 }
 
-// Compile-time loop: f(IC<B>{}), ..., f(IC<E-1>{}); the index is usable in template arguments.
-template <int I>
-struct IC { static constexpr int value = I; };
-template <int B, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (B < E) {
-        f(IC<B>{});
-        static_for<B + 1, E>(f);
-    }
-}
 
 struct WeightPipe {
     const char* src;           // next piece to fetch (wave-uniform)
@@ -847,8 +829,6 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
 // [NT x KT]-tile output in registers and takes every grid-th 16-sample k-step; each k-step's
 // NT + KT pieces go HBM -> LDS by global_load_lds into a ring of `depth` slots, depth-2 k-steps in
 // flight behind a counted vmcnt, one barrier per k-step.
-struct WgradSeg { const bf16x8* p; int tiles, n_true; };    // a T-frag buffer: its tile count, its true feature count
-struct WgradOut { float* G; int ld, col0; };                // where the (dY segment, X segment) block goes; G NULL = skip
 struct WgradArgs {
     WgradSeg A[2], B[2];       // dY side (output rows) and X side (output columns): up to two buffers each,
                                // concatenated along the feature axis (second may have 0 tiles)
@@ -859,22 +839,6 @@ struct WgradArgs {
     int depth;                 // ring slots: depth - 2 k-steps stay in flight
 };
 
-constexpr int kWgradLds = 156 * 1024;      // ring + landing zone for padding loads
-
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n in 0..63 (the instruction takes an immediate)
-__device__ __forceinline__ void wait_vmcnt(int n) {
-#define NERF_W1(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-#define NERF_W8(a, b, c, d, e, f, g, h) NERF_W1(a) NERF_W1(b) NERF_W1(c) NERF_W1(d) NERF_W1(e) NERF_W1(f) NERF_W1(g) NERF_W1(h)
-    switch (n) {
-        NERF_W8(0, 1, 2, 3, 4, 5, 6, 7) NERF_W8(8, 9, 10, 11, 12, 13, 14, 15)
-        NERF_W8(16, 17, 18, 19, 20, 21, 22, 23) NERF_W8(24, 25, 26, 27, 28, 29, 30, 31)
-        NERF_W8(32, 33, 34, 35, 36, 37, 38, 39) NERF_W8(40, 41, 42, 43, 44, 45, 46, 47)
-        NERF_W8(48, 49, 50, 51, 52, 53, 54, 55) NERF_W8(56, 57, 58, 59, 60, 61, 62, 63)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-#undef NERF_W8
-#undef NERF_W1
-}
 
 // GT > 0: the loads per wave and k-step are the compile-time GT (the host checks) and go out between the rows of
 // MFMAs; GT = 0: any count, all issued at the top of the k-step.
@@ -1126,210 +1090,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
 
 
 // ------------------------------------------------------------------------------------------------
-// Weight gradient from T-frag8 operands: the same streaming GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 x e4m3,
-// one E8M0 scale per operand lane).  A k-step is one block of 64 samples: per 32-feature tile two 1 KiB pieces (the
-// tile's two 32-sample blocks).  Operand lane map of the instruction (checked with exact data,
-// tools/microbench/mx_layout.hip): lane 32 kh + n holds row n; its bytes 0..15 and the bytes 0..15 of lane n's other
-// half form scale block 0 (scaled by the exponent lane n supplies), bytes 16..31 of both halves form scale block 1
-// (exponent supplied by lane 32 + n).  So lane 32 kh + n takes bytes 0..15 from the piece of sample block 2Q (the
-// 16 bytes the producing lane 32 kh + n wrote) and bytes 16..31 from the piece of block 2Q + 1, and supplies the
-// exponent of block 2Q + kh: a scale block is exactly one producer block.  Activations carry exponent 127.
-// Four waves own the whole [NT x KT] output; pieces and scale bytes of a k-step go HBM -> LDS by global_load_lds
-// into a ring (depth - 1 k-steps in flight behind a counted vmcnt), loads issued between the rows of MFMAs.
-typedef int v8i __attribute__((ext_vector_type(8)));
-struct Wgrad8Args {
-    WgradSeg A[2], B[2];           // dY side / X side segments (p = e4m3 data)
-    const unsigned char* Asc[2];   // scale bytes of the dY segments
-    WgradOut out[2][2];
-    float* gb[2];
-    int64_t nblk;                  // blocks of 64 samples = k-steps
-    int NT, KT, WN, WK;
-    int depth;
-};
-constexpr int kWg8MaxLoads = 10;   // data loads per wave and k-step (2 (NT + KT) pieces over 4 waves), + 1 for scale bytes
-
-template <int NTW, int KTW>
-__global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave / a.WK, wk = wave % a.WK;
-    const int C = a.NT + a.KT;                      // tiles per sample block, dY tiles first
-    const int P = 2 * C;                            // data pieces per k-step: [block parity s][tile c]
-    const int G = (P + 3) / 4;                      // data loads per wave per k-step
-    const unsigned slot_bytes = (unsigned)(P + 1) * 1024;           // + 1 KiB: [segment][parity][256 B] scale bytes
-    LDS_AS char* ring = (LDS_AS char*)smem;
-    const int depth = a.depth;
-    LDS_AS char* scratch = ring + depth * slot_bytes;               // landing zone of padding loads, 1 KiB per wave
-    const int64_t q0 = blockIdx.x, qstride = gridDim.x;
-    const int64_t n = q0 < a.nblk ? (a.nblk - q0 + qstride - 1) / qstride : 0;
-
-    f32x16 acc[NTW][KTW];
-    float accb[NTW];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        accb[i] = 0.f;
-#pragma unroll
-        for (int j = 0; j < KTW; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    }
-    const bool do_bias = (a.gb[0] != nullptr || a.gb[1] != nullptr) && wk == 0;
-
-    // per-load source description, fixed for the sweep (wave-uniform): address = base + k-step * stride
-    const char* ld_base[kWg8MaxLoads];
-    int64_t ld_stride[kWg8MaxLoads];
-    unsigned ld_dst[kWg8MaxLoads];
-    bool ld_real[kWg8MaxLoads];
-#pragma unroll
-    for (int g = 0; g < kWg8MaxLoads; ++g) {
-        const int p = g * 4 + wave;
-        ld_real[g] = g < G && p < P;
-        const int sp = p >= C ? 1 : 0, c = p - sp * C;
-        const bool xside = c >= a.NT;
-        const int t = xside ? c - a.NT : c;
-        const WgradSeg s0 = xside ? a.B[0] : a.A[0], s1 = xside ? a.B[1] : a.A[1];
-        const bool second = t >= s0.tiles;
-        const WgradSeg sg = second ? s1 : s0;
-        const int lt = second ? t - s0.tiles : t;
-        ld_base[g] = ld_real[g] ? (const char*)sg.p + ((int64_t)sp * sg.tiles + lt) * 1024 : (const char*)a.A[0].p;
-        ld_stride[g] = ld_real[g] ? (int64_t)2 * sg.tiles * 1024 : 0;
-        ld_dst[g] = (unsigned)p * 1024;
-    }
-    // scale bytes: wave w fetches the 256 B of (segment w >> 1, block parity w & 1)
-    const bool sc_real = a.A[wave >> 1].tiles > 0 && a.Asc[wave >> 1] != nullptr;
-    const char* sc_base = sc_real ? (const char*)a.Asc[wave >> 1] + (wave & 1) * 256 : (const char*)a.A[0].p;
-    const unsigned sc_dst = (unsigned)P * 1024 + wave * 256;
-
-    int fill = 0, drain = 0;
-    int64_t is_q = 0;
-    LDS_AS char* is_slot = ring;
-    bool is_live = false;
-    auto begin_issue = [&](int64_t i) {
-        is_q = q0 + i * qstride;
-        is_slot = ring + (unsigned)fill * slot_bytes;
-        fill = fill + 1 == depth ? 0 : fill + 1;
-        is_live = i < n;
-    };
-    auto issue_load = [&](auto gc) {
-        constexpr int g = decltype(gc)::value;
-        if (g < G) {
-            const bool real = is_live && ld_real[g];
-            const char* src = real ? ld_base[g] + is_q * ld_stride[g] : (const char*)a.A[0].p;
-            LDS_AS char* dst = real ? is_slot + ld_dst[g] : scratch + wave * 1024;
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + lane * 16), (LDS_AS void*)dst, 16, 0, 0);
-        }
-    };
-    auto issue_scales = [&]() {
-        const bool real = is_live && sc_real;
-        const char* src = real ? sc_base + is_q * 512 : (const char*)a.A[0].p;
-        LDS_AS char* dst = real ? is_slot + sc_dst : scratch + wave * 1024;
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + lane * 4), (LDS_AS void*)dst, 4, 0, 0);
-    };
-    auto issue_all = [&](int64_t i) {
-        begin_issue(i);
-        issue_scales();
-        static_for<0, kWg8MaxLoads>([&](auto gc) __attribute__((always_inline)) { issue_load(gc); });
-    };
-    const int GL = G + 1;                           // vector-memory operations per wave per k-step
-
-    // which segment / local tile each owned output row is, fixed for the sweep
-    int a_seg[NTW], a_lt[NTW], a_c[NTW];
-#pragma unroll
-    for (int ii = 0; ii < NTW; ++ii) {
-        int nt = wn * NTW + ii;
-        if (nt >= a.NT) nt = 0;
-        a_c[ii] = nt;
-        a_seg[ii] = nt >= a.A[0].tiles ? 1 : 0;
-        a_lt[ii] = a_seg[ii] ? nt - a.A[0].tiles : nt;
-    }
-    const int n_lo = lane & 31, kh = lane >> 5;
-
-    for (int i = 0; i < depth - 1; ++i) issue_all(i);
-    for (int64_t i = 0; i < n; ++i) {
-        wait_vmcnt((depth - 2) * GL);               // this wave's part of k-step i has landed
-        __builtin_amdgcn_s_barrier();               // everyone's has; everyone is done reading k-step i - 1's slot
-        LDS_AS const char* slot = ring + (unsigned)drain * slot_bytes;
-        drain = drain + 1 == depth ? 0 : drain + 1;
-        v8i A[NTW], B[KTW];
-        int SA[NTW];
-        float sc0[NTW], sc1[NTW];
-#pragma unroll
-        for (int ii = 0; ii < NTW; ++ii) {
-            const u32x4 lo = *(LDS_AS const u32x4*)(slot + a_c[ii] * 1024 + lane * 16);
-            const u32x4 hi = *(LDS_AS const u32x4*)(slot + (C + a_c[ii]) * 1024 + lane * 16);
-            A[ii] = (v8i){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-            LDS_AS const unsigned char* sp = (LDS_AS const unsigned char*)(slot + P * 1024 + a_seg[ii] * 512 + n_lo * 8 + a_lt[ii]);
-            const unsigned e0 = sp[0], e1 = sp[256];                     // exponents of blocks 2Q and 2Q + 1
-            SA[ii] = (int)(kh ? e1 : e0);
-            sc0[ii] = __uint_as_float(e0 << 23);
-            sc1[ii] = __uint_as_float(e1 << 23);
-        }
-#pragma unroll
-        for (int j = 0; j < KTW; ++j) {
-            int kt = wk * KTW + j;
-            if (kt >= a.KT) kt = 0;
-            const u32x4 lo = *(LDS_AS const u32x4*)(slot + (a.NT + kt) * 1024 + lane * 16);
-            const u32x4 hi = *(LDS_AS const u32x4*)(slot + (C + a.NT + kt) * 1024 + lane * 16);
-            B[j] = (v8i){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-        }
-        begin_issue(i + depth - 1);
-        issue_scales();
-        static_for<0, NTW>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int ii = decltype(ic)::value;
-            static_for<0, kWg8MaxLoads>([&](auto gc) __attribute__((always_inline)) {
-                constexpr int g = decltype(gc)::value;
-                if constexpr ((g * NTW) / kWg8MaxLoads == ii) issue_load(gc);
-            });
-#pragma unroll
-            for (int j = 0; j < KTW; ++j)
-                acc[ii][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[ii], B[j], acc[ii][j], 0, 0, 0, SA[ii], 0, 127);
-            if (do_bias) {          // column sums of dY (bias gradient) on the vector ALU, by the waves that own them
-                typedef float f32x2_ __attribute__((ext_vector_type(2)));
-                float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x2_ l0 = __builtin_amdgcn_cvt_pk_f32_fp8(A[ii][q], false), h0 = __builtin_amdgcn_cvt_pk_f32_fp8(A[ii][q], true);
-                    const f32x2_ l1 = __builtin_amdgcn_cvt_pk_f32_fp8(A[ii][4 + q], false), h1 = __builtin_amdgcn_cvt_pk_f32_fp8(A[ii][4 + q], true);
-                    s0 += (l0[0] + l0[1]) + (h0[0] + h0[1]);
-                    s1 += (l1[0] + l1[1]) + (h1[0] + h1[1]);
-                }
-                accb[ii] += s0 * sc0[ii] + s1 * sc1[ii];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS write may outlive the workgroup
-
-    const int h = lane >> 5, c = lane & 31;
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        const int nt = wn * NTW + i;
-        if (nt >= a.NT) continue;
-        const int sa = nt >= a.A[0].tiles, lt = sa ? nt - a.A[0].tiles : nt;
-#pragma unroll
-        for (int j = 0; j < KTW; ++j) {
-            const int kt = wk * KTW + j;
-            if (kt >= a.KT) continue;
-            const int sb = kt >= a.B[0].tiles, lk = sb ? kt - a.B[0].tiles : kt;
-            const WgradOut o = a.out[sa][sb];
-            const int k = lk * 32 + c;
-            if (o.G == nullptr || k >= a.B[sb].n_true) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int nn = lt * 32 + acc_row(r, h);
-                if (nn < a.A[sa].n_true) atomicAdd(&o.G[(int64_t)nn * o.ld + o.col0 + k], acc[i][j][r]);
-            }
-        }
-        if (do_bias && a.gb[sa] != nullptr) {
-            const int nn = lt * 32 + c;
-            if (nn < a.A[sa].n_true) atomicAdd(&a.gb[sa][nn], accb[i]);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Weight packing.  One thread per 16-byte fragment element group.
 // Forward stream of one layer: pieces [nt][ks], lane (row r = l&31, half h): element j is
 // W[32 nt + r][col(16 ks + frag_feat(j,h))]; the padded k axis is [segment A | segment B].
@@ -1569,17 +1329,6 @@ static inline bool make_dims(const nerf_mlp_dims* d, HostDims* o) {
     X(5, 6, 2, 2, true)         /* SAR: H=156 W=180 L=4 (params.yaml sar)  */ \
     X(2, 1, 2, 2, true)         /* SAR: H=64  W<=32 L=4 (small test net)   */
 
-// Raise a kernel's dynamic-LDS limit once per device (the attribute belongs to the device's copy of the code
-// object; a process may drive several devices).
-static bool allow_dynamic_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done_mask) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    const unsigned long long bit = 1ull << dev;
-    if (done_mask.load(std::memory_order_acquire) & bit) return true;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
-    done_mask.fetch_or(bit, std::memory_order_release);
-    return true;
-}
 
 template <class N, bool SAVE>
 static int launch_fwd_t(const MlpFwdArgs& a, hipStream_t st) {
@@ -1834,70 +1583,6 @@ static int launch_wgrad(const WgradArgs& a, unsigned grid, size_t lds, hipStream
 }
 
 
-template <int NTW, int KTW>
-static int launch_wgrad8(const Wgrad8Args& a, unsigned grid, size_t lds, hipStream_t st) {
-    static std::atomic<unsigned long long> done{0};
-    if (!allow_dynamic_lds((const void*)mlp_wgrad8_kernel<NTW, KTW>, kWgradLds, done)) return NERF_ERR_LAUNCH;
-    hipLaunchKernelGGL((mlp_wgrad8_kernel<NTW, KTW>), dim3(grid), dim3(256), lds, st, a);
-    return nerf_launch_status();
-}
-
-// Split NT x KT output tiles over 4 waves (WN x WK) for the e4m3 kernel: the instantiation with the fewest tiles.
-static bool wgrad8_config(int NT, int KT, int* WN, int* WK, int* tn, int* tk) {
-    static const int kSplit[3][2] = {{2, 2}, {4, 1}, {1, 4}};
-    static const int kTmpl[9][2] = {{1, 1}, {1, 2}, {2, 2}, {2, 3}, {3, 3}, {4, 4}, {4, 5}, {5, 3}, {5, 4}};
-    int best = 1 << 30;
-    *tn = *tk = 0;
-    for (const auto& sp : kSplit) {
-        const int ntw = (NT + sp[0] - 1) / sp[0], ktw = (KT + sp[1] - 1) / sp[1];
-        for (const auto& t : kTmpl)
-            if (t[0] >= ntw && t[1] >= ktw && t[0] * t[1] < best) {
-                best = t[0] * t[1]; *tn = t[0]; *tk = t[1]; *WN = sp[0]; *WK = sp[1];
-            }
-    }
-    return *tn != 0;
-}
-
-static int wgrad8_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint, hipStream_t st) {
-    Wgrad8Args a;
-    a.NT = a.KT = 0;
-    for (int i = 0; i < 2; ++i) {
-        const int nf = d->dy_feat[i], kf = d->x_feat[i];
-        a.A[i] = {(const bf16x8*)d->dy[i], nf / 32, d->dy_true[i]};
-        a.B[i] = {(const bf16x8*)d->x[i], kf / 32, d->x_true[i]};
-        a.Asc[i] = (const unsigned char*)d->dy_scale[i];
-        if (nf > 0 && a.Asc[i] == nullptr) return NERF_ERR_ARG;
-        if (nf / 32 > 8) return NERF_ERR_SIZE;              // 8 scale bytes per feature row and sample block
-        a.gb[i] = nf ? d->gb[i] : nullptr;
-        a.NT += nf / 32;
-        a.KT += kf / 32;
-        for (int j = 0; j < 2; ++j) a.out[i][j] = {d->G[i][j], d->ld[i][j], d->col0[i][j]};
-    }
-    a.nblk = ((n_samples + 255) / 256) * 4;
-    int tn = 0, tk = 0;
-    if (!wgrad8_config(a.NT, a.KT, &a.WN, &a.WK, &tn, &tk)) return NERF_ERR_SIZE;
-    const int pieces = 2 * (a.NT + a.KT), loads = (pieces + 3) / 4;
-    if (loads > kWg8MaxLoads) return NERF_ERR_SIZE;
-    a.depth = (kWgradLds / 1024 - 4) / (pieces + 1);
-    if (a.depth > 6) a.depth = 6;
-    if ((a.depth - 2) * (loads + 1) > 63) a.depth = 63 / (loads + 1) + 2;
-    if (a.depth < 3) return NERF_ERR_SIZE;
-    unsigned grid = grid_hint > 0 ? (unsigned)grid_hint : 256u;
-    if ((int64_t)grid > a.nblk) grid = (unsigned)a.nblk;
-    const size_t lds = (size_t)(a.depth * (pieces + 1) + 4) * 1024;
-#define NERF_W8(n_, k_) if (tn == n_ && tk == k_) return launch_wgrad8<n_, k_>(a, grid, lds, st);
-    NERF_W8(1, 1) NERF_W8(1, 2) NERF_W8(2, 2) NERF_W8(2, 3) NERF_W8(3, 3) NERF_W8(4, 4) NERF_W8(4, 5) NERF_W8(5, 3) NERF_W8(5, 4)
-#undef NERF_W8
-    return NERF_ERR_SIZE;
-}
-
-// Which mlp_wgrad8_kernel<tn, tk> instantiation an e4m3 launch with these total padded feature counts uses.
-extern "C" int nerf_mlp_wgrad8_config(int n_feat, int k_feat, int* tn, int* tk) {
-    int wn, wk;
-    NERF_REQUIRE(tn && tk && n_feat > 0 && k_feat > 0 && n_feat % 32 == 0 && k_feat % 32 == 0);
-    return wgrad8_config(n_feat / 32, k_feat / 32, &wn, &wk, tn, tk) ? NERF_OK : NERF_ERR_SIZE;
-}
-
 // dW blocks for up to two dY buffers x two X buffers in one pass over the samples (each operand byte read once).
 extern "C" int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint, void* stream) {
     if (n_samples == 0) return NERF_OK;
@@ -1909,7 +1594,7 @@ extern "C" int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples,
         NERF_REQUIRE((nf == 0 || d->dy[i]) && (kf == 0 || d->x[i]) && d->dy_true[i] <= nf && d->x_true[i] <= kf);
     }
     NERF_REQUIRE(d->G[0][0] != nullptr);
-    if (d->tfrag_fmt == NERF_TFRAG_E4M3) return wgrad8_multi(d, n_samples, grid_hint, nerf_stream(stream));
+    if (d->tfrag_fmt == NERF_TFRAG_E4M3) return nerf_wgrad8_multi(d, n_samples, grid_hint, nerf_stream(stream));
     WgradArgs a;
     a.NT = a.KT = 0;
     for (int i = 0; i < 2; ++i) {

@@ -32,7 +32,7 @@ class WgradDesc(ctypes.Structure):
 
 _lib.register('nerf_mlp_wgrad_multi', c_int, [POINTER(WgradDesc), c_int64, c_int, _P])
 _lib.register('nerf_mlp_wgrad_config', c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)])
-_lib.register('nerf_mlp_wgrad8_config', c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)])
+_lib.register('nerf_mlp_wgrad8_config', c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)])
 _lib.register('nerf_mlp_wgrad', c_int, [_P, c_int, _P, c_int, c_int64, _P, c_int, c_int, c_int, c_int, _P, c_int, _P])
 
 STREAMED = (['density_net0.%d' % i for i in (0, 2, 4, 6)] + ['density_net1.%d' % i for i in (0, 2, 4, 6)]
@@ -280,9 +280,9 @@ def wgrad_kernel_name(n_feat, k_feat, fmt=0):
     """Symbol of the kernel instantiation that handles these feature counts."""
     key = (n_feat, k_feat, fmt)
     if key not in _WGRAD_KERNEL and fmt:
-        tn, tk = c_int(), c_int()
-        check(lib().nerf_mlp_wgrad8_config(n_feat, k_feat, ctypes.byref(tn), ctypes.byref(tk)))
-        _WGRAD_KERNEL[key] = 'mlp_wgrad8_kernel<%d, %d>' % (tn.value, tk.value)
+        tn, tk, gs = c_int(), c_int(), c_int()
+        check(lib().nerf_mlp_wgrad8_config(n_feat, k_feat, ctypes.byref(tn), ctypes.byref(tk), ctypes.byref(gs)))
+        _WGRAD_KERNEL[key] = 'mlp_wgrad8_kernel<%d, %d, %d>' % (tn.value, tk.value, gs.value)
     if key not in _WGRAD_KERNEL:
         nw, tn, tk, gt = c_int(), c_int(), c_int(), c_int()
         check(lib().nerf_mlp_wgrad_config(n_feat, k_feat, ctypes.byref(nw), ctypes.byref(tn), ctypes.byref(tk),

@@ -178,11 +178,11 @@ def tfrag8_to_dense(buf, F, scales=None):
 
 def block_scaled_e4m3(x):
     """The gradient copies' quantisation restated in torch: per (feature, block of 32 samples) an exponent
-    e = max(biased exponent of the largest magnitude - 7, 0), values stored as e4m3(x 2^(127 - e))."""
+    e = max(biased exponent of the largest magnitude - 7, 1), values stored as e4m3(x 2^(127 - e))."""
     M, F = x.shape
     xb = x.reshape(-1, 32, F)
     field = xb.abs().amax(dim=1, keepdim=True).contiguous().view(torch.int32) >> 23
-    e = (field - 7).clamp_min(0).float()
+    e = (field - 7).clamp_min(1).float()
     q = (xb * torch.exp2(127.0 - e)).to(torch.float8_e4m3fn).float() * torch.exp2(e - 127.0)
     return q.reshape(M, F)
 

@@ -18,6 +18,7 @@ def timeit(f, n=5):
     return e0.elapsed_time(e1) / n
 
 cfg = make_cfg('bf16')
+if os.environ.get('NERF_FMT'): cfg.wgrad_operands = os.environ['NERF_FMT']
 m = MipNeRF(cfg).cuda()
 if os.environ.get('NERF_ZERO'):
     for p_ in m.parameters():

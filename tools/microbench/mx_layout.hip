@@ -26,6 +26,14 @@ __global__ void mx_kernel(const v8i* a, const v8i* b, const int* sa, const int* 
     cv_out[2 * l] = p;
     p = __builtin_amdgcn_cvt_pk_fp8_f32(cv_in[2 * l], cv_in[2 * l + 1], 0x12345678, true);
     cv_out[2 * l + 1] = p;
+    if (l < 4) {        // the scaled conversion: does it divide or multiply by the scale operand?
+        typedef short v2s __attribute__((ext_vector_type(2)));
+        const float scale[4] = {2.f, 0.5f, 1.f, 4.f};
+        v2s o = {0x1111, 0x2222};
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(o, 3.25f, -24.f, scale[l], false);
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(o, 100.f, 0.3f, scale[l], true);
+        cv_out[128 + l] = (unsigned short)o[0] | ((int)o[1] << 16);
+    }
 }
 
 static unsigned char enc(int v) {            // small integers are exact in e4m3
@@ -44,16 +52,16 @@ static void run(const std::vector<unsigned char>& a, const std::vector<unsigned 
     static void *da = nullptr, *db, *dsa, *dsb, *dout, *dcv, *dco;
     if (!da) {
         (void)hipMalloc(&da, 2048); (void)hipMalloc(&db, 2048); (void)hipMalloc(&dsa, 256); (void)hipMalloc(&dsb, 256);
-        (void)hipMalloc(&dout, 2048 * 4); (void)hipMalloc(&dcv, 512); (void)hipMalloc(&dco, 512);
+        (void)hipMalloc(&dout, 2048 * 4); (void)hipMalloc(&dcv, 512); (void)hipMalloc(&dco, 528);
     }
     (void)hipMemcpy(da, a.data(), 2048, hipMemcpyHostToDevice); (void)hipMemcpy(db, b.data(), 2048, hipMemcpyHostToDevice);
     (void)hipMemcpy(dsa, sa.data(), 256, hipMemcpyHostToDevice); (void)hipMemcpy(dsb, sb.data(), 256, hipMemcpyHostToDevice);
     (void)hipMemcpy(dcv, cv.data(), 512, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(mx_kernel, dim3(1), dim3(64), 0, 0, (const v8i*)da, (const v8i*)db, (const int*)dsa, (const int*)dsb,
                        (float*)dout, (const float*)dcv, (int*)dco);
-    out.resize(2048); co.resize(128);
+    out.resize(2048); co.resize(132);
     if (hipMemcpy(out.data(), dout, 2048 * 4, hipMemcpyDeviceToHost) != hipSuccess) { printf("copy failed\n"); exit(1); }
-    (void)hipMemcpy(co.data(), dco, 512, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(co.data(), dco, 528, hipMemcpyDeviceToHost);
 }
 
 int main() {
@@ -124,6 +132,12 @@ int main() {
         const unsigned lo = (unsigned)co[2 * i], hi = (unsigned)co[2 * i + 1];
         printf("  (%g, %g): word_sel=0 -> %08x [%g %g], word_sel=1 -> %08x\n", cv[2 * i], cv[2 * i + 1], lo, dec(lo & 0xff),
                dec((lo >> 8) & 0xff), hi);
+    }
+    printf("cvt_scalef32_pk_fp8_f32 of (3.25, -24 | 100, 0.3):\n");
+    for (int l = 0; l < 4; ++l) {
+        const unsigned w = (unsigned)co[128 + l];
+        printf("  scale %g -> %08x = [%g %g | %g %g]\n", (const float[]){2.f, 0.5f, 1.f, 4.f}[l], w, dec(w & 0xff), dec((w >> 8) & 0xff),
+               dec((w >> 16) & 0xff), dec(w >> 24));
     }
     return 0;
 }
