@@ -98,6 +98,11 @@ def sar_pulse_step(model, batch, opt, world):
     return loss.detach()
 
 
+def mlp_default_operands():
+    from nerf_amd import mlp_bf16
+    return mlp_bf16.DEFAULT_WGRAD_OPERANDS
+
+
 def launch_ranks(n, argv):
     """Start n ranks of this script (one per GPU) and relay their output; nothing here touches a GPU."""
     import socket
@@ -162,6 +167,9 @@ def main():
     ap.add_argument('--chunk', type=int, default=65536, help='rays per forward/backward chunk')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--wgrad-operands', default=None, choices=['bf16', 'e4m3'],
+                    help='format of the saved weight-gradient operands (default: the library default, e4m3; the MLP '
+                         'itself computes in bf16 either way)')
     ap.add_argument('--rehearse-one-gpu', action='store_true',
                     help='N>1 ranks all on cuda:0 over gloo: a rehearsal of the multi-rank code path on a one-GPU box '
                          '(its numbers mean nothing)')
@@ -198,6 +206,7 @@ def main():
     torch.manual_seed(0)
     sar = args.workload == 'c4'
     cfg = make_sar_cfg(args.precision) if sar else make_cfg(args.precision)
+    cfg.wgrad_operands = args.wgrad_operands
     model = (SARNeRF(cfg) if sar else MipNeRF(cfg)).to(dev).train()
     if world > 1:                                    # identical replicas
         for p in model.parameters():
@@ -258,7 +267,9 @@ def main():
                                     'C2: forward-only hierarchical render') + ', coarse 64 + fine 128 samples/ray, '
                                    '8x256 MLP (colour width 128), L=10/4 posenc',
                        'rays_per_step_per_gpu': args.rays, 'global_rays_per_step': args.rays * world,
-                       'chunk_rays': args.chunk, 'parallelism': f'ray-sharded dp{world}, flat-bucket grad all-reduce',
+                       'chunk_rays': args.chunk,
+                       'wgrad_operands': args.wgrad_operands or mlp_default_operands(),
+                       'parallelism': f'ray-sharded dp{world}, flat-bucket grad all-reduce',
                        'loss': float(loss)},
         }
         if prof:
@@ -280,7 +291,7 @@ def main():
                     roof['stores'] = {'achieved': r['bytes'] / (r['ms'] * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                       'frac': r['bytes'] / (r['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       'algorithmic_bytes_per_launch': r['bytes'] / r['calls']}
-            roof.update(avg_launch_ms=avg_ms, launches_per_step=r['calls'] / args.steps, traffic=pmc_traffic(dom, args.rays) if args.chunk >= args.rays else None)
+            roof.update(avg_launch_ms=avg_ms, launches_per_step=r['calls'] / args.steps, traffic=pmc_traffic(dom, args.rays) if (args.chunk >= args.rays and args.wgrad_operands in (None, mlp_default_operands())) else None)
             out['roofline'] = roof
             mlp_flops = sum(prof[k]['flops'] for k in prof if k.startswith('mlp_'))
             mlp_ms = sum(prof[k]['ms'] for k in prof if k.startswith('mlp_'))
