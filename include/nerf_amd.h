@@ -221,7 +221,9 @@ int nerf_layernorm_bwd(const float* x, const float* gamma, const float* gy, cons
 
 /* Logical layer sizes: enc_dim = 6 (max_deg - min_deg), view_dim = 3 + 6 (viewdirs degrees),
  * hidden = config.hidden, width = config.num_samples (the colour layer's width upstream),
- * sar != 0 selects the SAR heads (LayerNorm before the density head, extra angle head). */
+ * sar != 0 selects the SAR heads (LayerNorm before the density head, extra angle head).
+ * view_dim = width = 0 selects the network without view directions (use_viewdirs = False, model.py:78-92,
+ * 283-302): no rgb_net0 / rgb_net1, every head reads the trunk output. */
 typedef struct nerf_mlp_dims {
     int enc_dim, view_dim, hidden, width, sar;
 } nerf_mlp_dims;
@@ -237,7 +239,9 @@ int nerf_mlp_sizes(const nerf_mlp_dims* dims, int64_t* wfwd_bytes, int64_t* wbwd
  * (rgb_net0 has no activation upstream, model.py:82-84, so the two layers are one affine map of [trunk | view]; the
  * caller forms the fp32 product, and the folded bias rgb_net1.0[:, :hidden] * b_rgb_net0 + b_rgb_net1 goes into the
  * constants block), [9] the density head row [1, hidden] (SAR: final_density.1 weight * LayerNorm gamma), [10] the
- * colour heads [3, width] (SAR: final_rgb and final_angle stacked, [5, width]).  Call after every optimizer step.
+ * colour heads [3, width] (SAR: final_rgb and final_angle stacked, [5, width]).  Without view directions [8] and
+ * [10] are unused (may be NULL) and [9] is the head tile [4, hidden] = [density row; final_rgb] (SAR: [6, hidden],
+ * final_angle below); its biases go into the constants block in the same row order.  Call after every optimizer step.
  *                                                  reference: the nn.Linear weights of model.py:54-93 */
 int nerf_mlp_pack(const nerf_mlp_dims* dims, const float* const* weights, void* wfwd, void* wbwd,
                   void* stream);
@@ -274,7 +278,8 @@ int nerf_view_frag(const float* dirs, int64_t n_rays, int min_deg, int max_deg, 
  * ceil(features / 64) * 256 bytes; [18] unused, may be NULL), [20] / [21] the position encoding and
  * view features as transposed fragments, [22] (SAR only) the trunk output in fragment order (nblk * H_padded
  * * 128 bytes).  With tfrag_fmt = NERF_TFRAG_E4M3 the transposed-fragment buffers [0..9], [20], [21] hold e4m3 and
- * need half the bytes.                                 reference: model.py:117-132, 343-359 */
+ * need half the bytes.  Without view directions view_frag, [9], [19] and [21] are unused (may be NULL).
+ *                                                      reference: model.py:117-132, 343-359 */
 int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* consts, const void* enc_frag,
                  const void* view_frag, int64_t n_samples, int ray_div, int64_t n_rays, void* const* acts,
                  int tfrag_fmt, float* raw_density, float* raw_rgb, float* raw_angle, float* ln_stats, void* stream);
@@ -289,7 +294,8 @@ int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* const
  * constants block are required too; the density head tile then carries rows g*rstd, g*rstd*mean, g, from which
  * the LayerNorm and density-weight gradients are assembled (NeRF: pass NULL for them).  With tfrag_fmt =
  * NERF_TFRAG_E4M3 every dys[i] holds e4m3 (half the bytes) and dys[12 + i] (nblk * 2 * 256 bytes each) receives
- * its scale bytes.
+ * its scale bytes.  Without view directions there is one head tile, dys[11] (rows: density, rgb 1..3, SAR angle 4..5
+ * and the two LayerNorm sums g*rstd*mean, g in rows 6..7); dys[9], dys[10] are unused (may be NULL).
  *                              reference: autograd of model.py:117-132 (aten::mm, threshold_backward) */
 int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, const float* consts, int64_t n_samples,
                  const float* g_density, const float* g_rgb, const float* g_angle, const float* raw_density,

@@ -19,14 +19,17 @@ LIB = os.path.join(LIBDIR, 'libnerf_amd.so')
 COMMON = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 # translation unit -> extra flags.  The sampling / compositing kernels must round every fp32
 # operation separately (parity with the reference's op-by-op torch arithmetic).
+# mlp_bf16.hip is compiled in parts (-DNERF_NET_PART=p): the chain kernels of each large network geometry take
+# minutes to compile, so each gets its own object and they build side by side.
 UNITS = {
-    'api.hip': [],
-    'sampling.hip': ['-ffp-contract=off'],
-    'composite.hip': ['-ffp-contract=off'],
-    'gemm_f32.hip': [],
-    'mlp_bf16.hip': [],      # default contraction: MFMA chain, fp32 epilogues
-    'wgrad8.hip': [],
+    'api.o': ('api.hip', []),
+    'sampling.o': ('sampling.hip', ['-ffp-contract=off']),
+    'composite.o': ('composite.hip', ['-ffp-contract=off']),
+    'gemm_f32.o': ('gemm_f32.hip', []),
+    'wgrad8.o': ('wgrad8.hip', []),
 }
+UNITS.update({'mlp_bf16_p%d.o' % p: ('mlp_bf16.hip', ['-DNERF_NET_PART=%d' % p]) for p in range(8)})   # default contraction
+JOBS = int(os.environ.get('MAX_JOBS', '8'))
 
 
 def _hipcc():
@@ -49,21 +52,22 @@ def build(force=False, verbose=True):
     headers.append(os.path.join(os.path.dirname(HERE), 'include', 'nerf_amd.h'))
     headers.append(os.path.abspath(__file__))
     jobs, objs = [], []
-    for unit, extra in UNITS.items():
+    for name, (unit, extra) in UNITS.items():
         src = os.path.join(CSRC, unit)
-        if not os.path.exists(src):
-            continue
-        obj = os.path.join(OBJDIR, unit.replace('.hip', '.o'))
+        obj = os.path.join(OBJDIR, name)
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
             jobs.append([_hipcc()] + COMMON + extra + ['-c', src, '-o', obj])
+    for f in os.listdir(OBJDIR):                      # objects of an older unit list must not be linked
+        if f.endswith('.o') and f not in UNITS:
+            os.remove(os.path.join(OBJDIR, f))
 
     def run(cmd):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(JOBS, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
         run([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)

@@ -39,6 +39,14 @@
 #include "common.h"
 #include "mlp_frag.h"
 
+// This file can be compiled in parts (-DNERF_NET_PART=p, one object each) so that the chain kernels of the
+// network geometries build in parallel: part 0 holds the C entry points, weight packing and encoders plus the small
+// networks, parts 1..6 one large network each, part 7 the bf16 weight-gradient kernels.  Undefined = everything.
+#ifndef NERF_NET_PART
+#define NERF_NET_PART -1
+#endif
+#define NERF_PART_IS(p) (NERF_NET_PART == -1 || NERF_NET_PART == (p))
+
 
 // max(x, 0) as one v_med3_f32 (no NaN canonicalisation pass in front of it)
 __device__ __forceinline__ float relu_f(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
@@ -190,10 +198,13 @@ constexpr int stage_count(int tiles) { return (tiles + kTPS - 1) / kTPS; }
 // Network geometry (compile time).  HT/WT: 32-row tiles of the hidden width / colour-layer width;
 // DKS/VKS: 16-feature k-steps of the (padded) position / view encodings.
 // F8: the saved weight-gradient operands are T-frag8 (e4m3) instead of bf16 T-frags.
+// WT = 0 (and VKS = 0): the network without view directions (model.py:78-92, 283-302): no colour layer; density,
+// colour (and SAR angle) heads are rows 0, 1..3 (, 4..5) of ONE head tile on the trunk output.
 template <int HT_, int WT_, int DKS_, int VKS_, bool SAR_, bool F8_ = false>
 struct Net {
     static constexpr int HT = HT_, WT = WT_, DKS = DKS_, VKS = VKS_;
-    static constexpr bool SAR = SAR_, F8 = F8_;
+    static constexpr bool SAR = SAR_, F8 = F8_, VIEW = WT_ > 0;
+    static_assert(VIEW || VKS_ == 0, "a network without view directions has no view features");
     static constexpr int TPIECES = F8_ ? 1 : 2;          // stores of one finished tile's transposed copy
     static constexpr int HKS = 2 * HT, WKS = 2 * WT, HP = 32 * HT, WP = 32 * WT;
     static constexpr int NHEAD = SAR ? 5 : 3;            // rgb (3) [+ angle (2)]
@@ -206,14 +217,15 @@ struct Net {
     static constexpr int C_TOTAL = C_SC + 16;
     static constexpr int SLOT_KS = HKS + (DKS > VKS ? DKS : VKS);
     static constexpr int FWD_LDS = C_TOTAL * 4 + (kRing * kTPS * SLOT_KS + 1) * 1024;   // + 1 KiB landing zone
-    static constexpr int BWD_SLOT_KS = HKS > (WKS + 1) ? HKS : (WKS + 1);
+    static constexpr int BWD_SLOT_KS = (!VIEW || HKS > (WKS + 1)) ? HKS : (WKS + 1);
     static constexpr int BWD_LDS = (kRing * kTPS * BWD_SLOT_KS + 1) * 1024;
     // pieces (1 KiB) in the packed streams
     // forward: L0, L1-3, L4, L5-7, density head tile, folded colour layer, rgb/angle head tile
     static constexpr int FWD_PIECES = HT * DKS + 3 * HT * HKS + HT * (HKS + DKS) + 3 * HT * HKS + HKS +
                                       WT * (HKS + VKS) + WKS;
-    // backward: heads^T (1 k-step), folded colour layer^T (+1 k-step: density head row), L7..L5^T, L4^T, L3..L1^T
-    static constexpr int BWD_PIECES = WT * 1 + HT * (WKS + 1) + 7 * HT * HKS;
+    // backward: heads^T (1 k-step), folded colour layer^T (+1 k-step: density head row), L7..L5^T, L4^T, L3..L1^T;
+    // without view directions: head tile^T (HT tiles, 1 k-step), L7..L1^T
+    static constexpr int BWD_PIECES = VIEW ? WT * 1 + HT * (WKS + 1) + 7 * HT * HKS : HT * 1 + 7 * HT * HKS;
 };
 
 struct MlpFwdArgs {
@@ -259,7 +271,7 @@ struct StageDesc { int ks, pre, xloads, stores; };      // ks = pieces of the wh
 template <class N, bool SAVE>
 constexpr StageDesc fwd_stage(int i) {
     constexpr int kL = 11;
-    const int tiles[kL] = {N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, 1, N::WT, 1};
+    const int tiles[kL] = {N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, 1, N::WT, N::VIEW ? 1 : 0};
     const int ks[kL] = {N::DKS, N::HKS, N::HKS, N::HKS, N::HKS + N::DKS, N::HKS, N::HKS, N::HKS, N::HKS,
                         N::HKS + N::VKS, N::WKS};
     // 0 head (nothing saved), 2 saved + sign words, 3 as 2 + a frag-order copy (SAR trunk output)
@@ -285,9 +297,9 @@ constexpr StageDesc fwd_stage(int i) {
 // layer's scale bytes behind the last tile); the first stage of a layer also loads the next masked layer's sign words.
 template <class N>
 constexpr StageDesc bwd_stage(int i) {
-    constexpr int kL = 9;
-    const int tiles[kL] = {N::WT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT};
-    const int ks[kL] = {1, N::WKS + 1, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS};
+    constexpr int kL = 9;       // (without view directions the first entry has no tiles and the second one k-step)
+    const int tiles[kL + 1] = {N::WT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, N::HT, 0};
+    const int ks[kL] = {1, N::VIEW ? N::WKS + 1 : 1, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS, N::HKS};
     const bool masked[kL + 1] = {true, true, true, true, true, true, true, true, true, false};
     if (i < 0) return {0, 0, 0, 0};
     for (int l = 0; l < kL; ++l) {
@@ -296,7 +308,7 @@ constexpr StageDesc bwd_stage(int i) {
             int st = 0;
             for (int t = t0; t < t1; ++t) st += t > 0 ? N::TPIECES : 0;
             // (the previous layer's last tile: 2 bf16 pieces, or 1 e4m3 piece + the scale bytes)
-            return {ks[l] * (t1 - t0), (i == 0 && l > 0) ? 2 : 0, (i == 0 && masked[l + 1]) ? (tiles[l + 1] + 1) / 2 : 0, st};
+            return {ks[l] * (t1 - t0), (i == 0 && l > (N::VIEW ? 0 : 1)) ? 2 : 0, (i == 0 && masked[l + 1]) ? (tiles[l + 1] + 1) / 2 : 0, st};
         }
         i -= stage_count(tiles[l]);
     }
@@ -538,11 +550,11 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     const int64_t b32 = blk * 2 + ct;
     bf16x8 P[2];
     make_perm(P, lane);
-    bf16x8 enc[N::DKS], view[N::VKS];
+    bf16x8 enc[N::DKS], view[N::VIEW ? N::VKS : 1];
 #pragma unroll
     for (int ks = 0; ks < N::DKS; ++ks) enc[ks] = a.enc[((blk * N::DKS + ks) * 2 + ct) * 64 + lane];
     const int64_t m = blk * 64 + ct * 32 + c;
-    {
+    if constexpr (N::VIEW) {
         const int64_t mm = m < a.M ? m : a.M - 1;
         const int64_t ray = N::SAR ? (mm % a.ray_div) : (mm / a.ray_div);
 #pragma unroll
@@ -559,7 +571,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
             else emit_tfrag(a.t_enc, b32, (N::DKS + 1) / 2, i, lane, enc[2 * i], hi, P);
         }
 #pragma unroll
-        for (int i = 0; i < (N::VKS + 1) / 2; ++i) {
+        for (int i = 0; i < (N::VKS + 1) / 2; ++i) {      // (no iterations without view directions)
             const bf16x8 hi = 2 * i + 1 < N::VKS ? view[2 * i + 1 < N::VKS ? 2 * i + 1 : 0] : zero;
             if constexpr (N::F8) emit_tfrag8(a.t_view, b32, (N::VKS + 1) / 2, i, lane, view[2 * i], hi, P);
             else emit_tfrag(a.t_view, b32, (N::VKS + 1) / 2, i, lane, view[2 * i], hi, P);
@@ -577,7 +589,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
 
     float hd_density[4], hd_colour[4], ln[2] = {0.f, 0.f};
     bf16x8 xa[N::HKS], xb[N::HKS], none[1];
-    bf16x8 xw[N::WKS];
+    bf16x8 xw[N::VIEW ? N::WKS : 2];     // (without view directions: the unused output operand of the head tile)
     constexpr int HKS = N::HKS, HT = N::HT, HS = stage_count(N::HT), WS = stage_count(N::WT);
     const float* bias = cst + N::C_BIAS;
     // density_net0: enc -> X0 -> X1 -> X2 -> X3
@@ -590,12 +602,23 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     fwd_layer<N, SAVE, 5 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 5 * N::HP, h, a.tx[5], a.mask[5], b32, P, hd_density, ln);
     fwd_layer<N, SAVE, 6 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 6 * N::HP, h, a.tx[6], a.mask[6], b32, P, hd_density, ln);
     fwd_layer<N, SAVE, 7 * HS, HT, HKS, 0, true, EPI_TRUNK>(pipe, xa, none, xb, bias + 7 * N::HP, h, a.tx[7], a.mask[7], b32, P, hd_density, ln, a.x7_frag);
-    // final_density as one more output tile on X7 (row 0)
+    // final_density as one more output tile on X7 (row 0; without view directions rows 1..3 are final_rgb and rows
+    // 4..5 final_angle: all heads sit on the trunk output)
     fwd_layer<N, SAVE, 8 * HS, 1, HKS, 0, false, EPI_HEAD>(pipe, xb, none, xw, cst + N::C_BIASD, h, nullptr, nullptr, b32, P, hd_density, ln);
-    // rgb_net0 folded into rgb_net1: [X7 | view] -> X9 ; final_rgb (+ final_angle) as one output tile on X9 (rows 0..4)
-    fwd_layer<N, SAVE, 8 * HS + 1, N::WT, HKS, N::VKS, true, EPI_PLAIN>(pipe, xb, view, xw, cst + N::C_BIAS9, h, a.tx[9], a.mask[9], b32, P, hd_colour, ln);
-    fwd_layer<N, SAVE, 8 * HS + 1 + WS, 1, N::WKS, 0, false, EPI_HEAD>(pipe, xw, none, xa, cst + N::C_BIASH, h, nullptr, nullptr, b32, P, hd_colour, ln);
-    static_assert(fwd_stage<N, SAVE>(8 * HS + 2 + WS).ks == 0 && fwd_stage<N, SAVE>(8 * HS + 1 + WS).ks == N::WKS, "stage table out of step");
+    if constexpr (N::VIEW) {
+        // rgb_net0 folded into rgb_net1: [X7 | view] -> X9 ; final_rgb (+ final_angle) as one output tile on X9 (rows 0..4)
+        fwd_layer<N, SAVE, 8 * HS + 1, N::WT, HKS, N::VKS, true, EPI_PLAIN>(pipe, xb, view, xw, cst + N::C_BIAS9, h, a.tx[9], a.mask[9], b32, P, hd_colour, ln);
+        fwd_layer<N, SAVE, 8 * HS + 1 + WS, 1, N::WKS, 0, false, EPI_HEAD>(pipe, xw, none, xa, cst + N::C_BIASH, h, nullptr, nullptr, b32, P, hd_colour, ln);
+        static_assert(fwd_stage<N, SAVE>(8 * HS + 2 + WS).ks == 0 && fwd_stage<N, SAVE>(8 * HS + 1 + WS).ks == N::WKS, "stage table out of step");
+    } else {
+        static_assert(fwd_stage<N, SAVE>(8 * HS + 1).ks == 0 && fwd_stage<N, SAVE>(8 * HS).ks == HKS, "stage table out of step");
+        // lane half 0: rows 0..3 = density, rgb; lane half 1: rows 4..5 = angle.  Bring them into the places the
+        // output code below reads: hd_colour[0..2] rgb, hd_colour[3] angle 0, lane half 1's hd_colour[0] angle 1
+        hd_colour[0] = hd_density[1];                       // lane half 0: red; lane half 1: row 5 = angle 1
+        hd_colour[1] = hd_density[2];
+        hd_colour[2] = hd_density[3];
+        hd_colour[3] = __shfl_xor(hd_density[0], 32);       // row 4 = angle 0, held by lane half 1
+    }
 
     // outputs.  Lane half 0 holds rows 0..3 of a head tile, half 1 rows 4..7.
     const float* sc = cst + N::C_SC;
@@ -768,9 +791,13 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
             const float B = gd * rstd * rstd * (a.raw_density[m] - sc[7]) * sc[8];
             c1 = -B;
             c0 = B * mean - A;
-            if (h == 0) {
+            if (N::VIEW && h == 0) {
                 dd[1] = (__bf16)(gd * rstd * mean);
                 dd[2] = (__bf16)gd;
+            }
+            if (!N::VIEW && h == 1) {       // one head tile: these sums ride in rows 6 and 7 (zero weight rows)
+                dz[2] = (__bf16)(gd * rstd * mean);
+                dz[3] = (__bf16)gd;
             }
             gd *= rstd;
         }
@@ -778,24 +805,39 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
                 const float sg = a.raw_rgb[m * 3 + o];
-                dz[o] = (__bf16)(a.g_rgb[m * 3 + o] * sg * (1.f - sg));
+                dz[(N::VIEW ? 0 : 1) + o] = (__bf16)(a.g_rgb[m * 3 + o] * sg * (1.f - sg));
             }
-            dd[0] = (__bf16)gd;
+            if (N::VIEW) dd[0] = (__bf16)gd;
+            else dz[0] = (__bf16)gd;
         }
-        if constexpr (N::SAR) {     // angle heads: rows 3 (lane half 0, element 3) and 4 (lane half 1, element 0)
+        if constexpr (N::SAR && N::VIEW) {     // angle heads: rows 3 (lane half 0, element 3) and 4 (lane half 1, element 0)
             const float sg = a.raw_angle[m * 2 + h];
             dz[h == 0 ? 3 : 0] = (__bf16)(a.g_angle[m * 2 + h] * sg * (1.f - sg));
         }
-    }
-    unsigned kw9[WW], kwa[HW], kwb[HW], nokw[1] = {0u};
+        if constexpr (N::SAR && !N::VIEW) {    // rows 4 and 5: lane half 1, elements 0 and 1
+            if (h == 1) {
 #pragma unroll
-    for (int i = 0; i < WW; ++i) kw9[i] = a.mask[9][(b32 * WW + i) * 64 + lane];
-    if constexpr (N::F8) {
-        store_scales(a.tsc[10], b32, lane, emit_tfrag8_scaled(a.tdy_hd, b32, 1, 0, lane, dz, zero, P), 0u);
-        store_scales(a.tsc[11], b32, lane, emit_tfrag8_scaled(a.tdy_dens, b32, 1, 0, lane, dd, zero, P), 0u);
+                for (int o = 0; o < 2; ++o) {
+                    const float sg = a.raw_angle[m * 2 + o];
+                    dz[o] = (__bf16)(a.g_angle[m * 2 + o] * sg * (1.f - sg));
+                }
+            }
+        }
+    }
+    unsigned kw9[WW > 0 ? WW : 1], kwa[HW], kwb[HW], nokw[1] = {0u};
+    if constexpr (N::VIEW) {
+#pragma unroll
+        for (int i = 0; i < WW; ++i) kw9[i] = a.mask[9][(b32 * WW + i) * 64 + lane];
     } else {
-        emit_tfrag(a.tdy_hd, b32, 1, 0, lane, dz, zero, P);
-        emit_tfrag(a.tdy_dens, b32, 1, 0, lane, dd, zero, P);
+#pragma unroll
+        for (int i = 0; i < HW; ++i) kwa[i] = a.mask[7][(b32 * HW + i) * 64 + lane];
+    }
+    if constexpr (N::F8) {
+        if constexpr (N::VIEW) store_scales(a.tsc[10], b32, lane, emit_tfrag8_scaled(a.tdy_hd, b32, 1, 0, lane, dz, zero, P), 0u);
+        store_scales(a.tsc[11], b32, lane, emit_tfrag8_scaled(a.tdy_dens, b32, 1, 0, lane, N::VIEW ? dd : dz, zero, P), 0u);
+    } else {
+        if constexpr (N::VIEW) emit_tfrag(a.tdy_hd, b32, 1, 0, lane, dz, zero, P);
+        emit_tfrag(a.tdy_dens, b32, 1, 0, lane, N::VIEW ? dd : dz, zero, P);
     }
 
     WeightPipe pipe;
@@ -806,11 +848,16 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
     pipe.lane = lane;
     pipe.template prime<bwd_stage<N>(0).ks, bwd_stage<N>(1).ks, bwd_stage<N>(2).ks, bwd_stage<N>(3).ks>();
 
-    bf16x8 ga[HKS], gb[HKS], gw[WKS], none[1], dzv[1] = {dz}, ddv[1] = {dd};
-    // heads^T: dX9 = Wh^T dz, masked by X9 > 0 -> dY9
-    bwd_layer<N, 0, WT, 1, 0, true, HW>(pipe, dzv, none, gw, kw9, a.mask[7], kwa, a.tdy[9], a.tsc[9], b32, P);
-    // [folded colour layer (columns of X7 only) ; density head]^T: dX7 = (W9a W8)^T dY9 + wd^T dd, masked by X7 > 0 -> dY7
-    bwd_layer<N, WS, HT, WKS, 1, true, HW, N::SAR>(pipe, gw, ddv, gb, kwa, a.mask[6], kwb, a.tdy[7], a.tsc[7], b32, P, x7, c0, c1);
+    bf16x8 ga[HKS], gb[HKS], gw[N::VIEW ? WKS : 1], none[1], dzv[1] = {dz}, ddv[1] = {dd};
+    if constexpr (N::VIEW) {
+        // heads^T: dX9 = Wh^T dz, masked by X9 > 0 -> dY9
+        bwd_layer<N, 0, WT, 1, 0, true, HW>(pipe, dzv, none, gw, kw9, a.mask[7], kwa, a.tdy[9], a.tsc[9], b32, P);
+        // [folded colour layer (columns of X7 only) ; density head]^T: dX7 = (W9a W8)^T dY9 + wd^T dd, masked by X7 > 0 -> dY7
+        bwd_layer<N, WS, HT, WKS, 1, true, HW, N::SAR>(pipe, gw, ddv, gb, kwa, a.mask[6], kwb, a.tdy[7], a.tsc[7], b32, P, x7, c0, c1);
+    } else {
+        // head tile^T: dX7 = [wd; Wrgb; Wangle]^T dz, masked by X7 > 0 -> dY7
+        bwd_layer<N, 0, HT, 1, 0, true, HW, N::SAR>(pipe, dzv, none, gb, kwa, a.mask[6], kwb, a.tdy[7], a.tsc[7], b32, P, x7, c0, c1);
+    }
     bwd_layer<N, WS + 1 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[5], kwa, a.tdy[6], a.tsc[6], b32, P);
     bwd_layer<N, WS + 2 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[4], kwb, a.tdy[5], a.tsc[5], b32, P);
     bwd_layer<N, WS + 3 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[3], kwa, a.tdy[4], a.tsc[4], b32, P);
@@ -822,6 +869,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
     static_assert(bwd_stage<N>(WS + 8 * HS).ks == 0 && bwd_stage<N>(WS + 8 * HS - 1).ks != 0, "stage table out of step");
 }
 
+#if NERF_PART_IS(7)
 // ------------------------------------------------------------------------------------------------
 // Weight gradient: G[n][col0 + k] += sum_m dY[m][n] X[m][k], gb[n] += sum_m dY[m][n], both operands
 // given as T-frags, i.e. already in MFMA operand order for a reduction over samples.  Pure streaming
@@ -1089,6 +1137,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
 }
 
 
+#endif  // part 7 (continued below: its host side)
+
+#if NERF_PART_IS(0)
 // ------------------------------------------------------------------------------------------------
 // Weight packing.  One thread per 16-byte fragment element group.
 // Forward stream of one layer: pieces [nt][ks], lane (row r = l&31, half h): element j is
@@ -1305,6 +1356,8 @@ __global__ void view_frag_kernel(const float* __restrict__ dirs, int64_t n_rays,
     out[gid] = o;
 }
 
+#endif  // part 0 (continued below: the entry points)
+
 // ------------------------------------------------------------------------------------------------
 // Host side
 struct HostDims {
@@ -1313,22 +1366,29 @@ struct HostDims {
 };
 
 static inline bool make_dims(const nerf_mlp_dims* d, HostDims* o) {
-    if (!d || d->enc_dim <= 0 || d->view_dim <= 0 || d->hidden <= 0 || d->width <= 0) return false;
+    if (!d || d->enc_dim <= 0 || d->view_dim < 0 || d->hidden <= 0 || d->width < 0) return false;
+    if ((d->view_dim == 0) != (d->width == 0)) return false;     // both 0: the network without view directions
     o->D = d->enc_dim; o->V = d->view_dim; o->H = d->hidden; o->W = d->width; o->sar = d->sar;
     o->HT = (d->hidden + 31) / 32; o->WT = (d->width + 31) / 32;
     o->DKS = (d->enc_dim + 15) / 16; o->VKS = (d->view_dim + 15) / 16;
     return true;
 }
 
-// supported compile-time geometries
-#define NERF_NET_LIST(X)        \
-    X(8, 4, 4, 2, false)        /* H=256 W=128 L=10 (64+128 configuration) */ \
-    X(8, 2, 4, 2, false)        /* H=256 W=64  L=10 (64+64 configuration)  */ \
-    X(8, 4, 6, 2, false)        /* H=256 W=128 L=16 (params.yaml nerf)     */ \
+// supported compile-time geometries, by the part of the build that compiles their kernels
+#define NERF_NET_LIST_0(X)      \
     X(2, 1, 2, 2, false)        /* H=64  W<=32 L=4  (small test network)   */ \
-    X(5, 6, 2, 2, true)         /* SAR: H=156 W=180 L=4 (params.yaml sar)  */ \
-    X(2, 1, 2, 2, true)         /* SAR: H=64  W<=32 L=4 (small test net)   */
-
+    X(2, 1, 2, 2, true)         /* SAR: H=64  W<=32 L=4 (small test net)   */ \
+    X(2, 0, 2, 0, false)        /* H=64  L=4,  no view directions          */ \
+    X(2, 0, 2, 0, true)         /* SAR: H=64  L=4, no view directions      */
+#define NERF_NET_LIST_1(X) X(8, 4, 4, 2, false)        /* H=256 W=128 L=10 (64+128 configuration) */
+#define NERF_NET_LIST_2(X) X(8, 2, 4, 2, false)        /* H=256 W=64  L=10 (64+64 configuration)  */
+#define NERF_NET_LIST_3(X) X(8, 4, 6, 2, false)        /* H=256 W=128 L=16 (params.yaml nerf)     */
+#define NERF_NET_LIST_4(X) X(5, 6, 2, 2, true)         /* SAR: H=156 W=180 L=4 (params.yaml sar)  */
+#define NERF_NET_LIST_5(X) X(8, 0, 4, 0, false)        /* H=256 L=10, no view directions          */
+#define NERF_NET_LIST_6(X) X(5, 0, 2, 0, true)         /* SAR: H=156 L=4, no view directions      */
+#define NERF_NET_LIST_BIG(X) NERF_NET_LIST_1(X) NERF_NET_LIST_2(X) NERF_NET_LIST_3(X) NERF_NET_LIST_4(X) \
+                             NERF_NET_LIST_5(X) NERF_NET_LIST_6(X)
+#define NERF_NET_LIST(X) NERF_NET_LIST_0(X) NERF_NET_LIST_BIG(X)
 
 template <class N, bool SAVE>
 static int launch_fwd_t(const MlpFwdArgs& a, hipStream_t st) {
@@ -1338,9 +1398,44 @@ static int launch_fwd_t(const MlpFwdArgs& a, hipStream_t st) {
     return nerf_launch_status();
 }
 template <class N>
-static int launch_fwd(const MlpFwdArgs& a, hipStream_t st) {
+int launch_fwd(const MlpFwdArgs& a, hipStream_t st) {
     return a.tx[0] != nullptr ? launch_fwd_t<N, true>(a, st) : launch_fwd_t<N, false>(a, st);
 }
+
+template <class N>
+int launch_bwd(const MlpBwdArgs& a, hipStream_t st) {
+    static std::atomic<unsigned long long> done{0};
+    constexpr int lds = N::BWD_LDS;
+    if (!allow_dynamic_lds((const void*)mlp_bwd_kernel<N>, lds, done)) return NERF_ERR_LAUNCH;
+    hipLaunchKernelGGL((mlp_bwd_kernel<N>), dim3((unsigned)(a.nblk / 4)), dim3(64 * kWaves), lds, st, a);
+    return nerf_launch_status();
+}
+
+// The launchers of a part's networks are instantiated in that part; part 0 only refers to them.
+#define NERF_LAUNCHERS(kw_, ht_, wt_, dks_, vks_, sar_)                                                   \
+    kw_ template int launch_fwd<Net<ht_, wt_, dks_, vks_, sar_, false>>(const MlpFwdArgs&, hipStream_t);   \
+    kw_ template int launch_fwd<Net<ht_, wt_, dks_, vks_, sar_, true>>(const MlpFwdArgs&, hipStream_t);    \
+    kw_ template int launch_bwd<Net<ht_, wt_, dks_, vks_, sar_, false>>(const MlpBwdArgs&, hipStream_t);   \
+    kw_ template int launch_bwd<Net<ht_, wt_, dks_, vks_, sar_, true>>(const MlpBwdArgs&, hipStream_t);
+#define NERF_X_DEFINE(ht_, wt_, dks_, vks_, sar_) NERF_LAUNCHERS(, ht_, wt_, dks_, vks_, sar_)
+#define NERF_X_EXTERN(ht_, wt_, dks_, vks_, sar_) NERF_LAUNCHERS(extern, ht_, wt_, dks_, vks_, sar_)
+#if NERF_NET_PART == 0
+NERF_NET_LIST_BIG(NERF_X_EXTERN)
+#elif NERF_NET_PART == 1
+NERF_NET_LIST_1(NERF_X_DEFINE)
+#elif NERF_NET_PART == 2
+NERF_NET_LIST_2(NERF_X_DEFINE)
+#elif NERF_NET_PART == 3
+NERF_NET_LIST_3(NERF_X_DEFINE)
+#elif NERF_NET_PART == 4
+NERF_NET_LIST_4(NERF_X_DEFINE)
+#elif NERF_NET_PART == 5
+NERF_NET_LIST_5(NERF_X_DEFINE)
+#elif NERF_NET_PART == 6
+NERF_NET_LIST_6(NERF_X_DEFINE)
+#endif
+
+#if NERF_PART_IS(0)
 
 extern "C" int nerf_mlp_sizes(const nerf_mlp_dims* dims, int64_t* wfwd_bytes, int64_t* wbwd_bytes,
                               int64_t* consts_floats) {
@@ -1362,6 +1457,8 @@ extern "C" int nerf_mlp_sizes(const nerf_mlp_dims* dims, int64_t* wfwd_bytes, in
 // weights[11], all fp32 [out,in]: 0-3 density_net0.{0,2,4,6}, 4-7 density_net1.{0,2,4,6}, 8 the folded colour layer
 // [W, H+V] = [rgb_net1.0[:, :H] rgb_net0.0 | rgb_net1.0[:, H:]], 9 the density head row [1,H] (SAR: final_density
 // weight * LayerNorm gamma), 10 the colour heads [3,W] (SAR: final_rgb and final_angle stacked, [5,W]).
+// Without view directions (view_dim = width = 0): 8 and 10 are unused (may be NULL) and 9 is the head tile
+// [4,H] = [density row; final_rgb] (SAR: [6,H] with final_angle below).
 extern "C" int nerf_mlp_pack(const nerf_mlp_dims* dims, const float* const* weights, void* wfwd, void* wbwd,
                              void* stream) {
     HostDims d;
@@ -1390,19 +1487,27 @@ extern "C" int nerf_mlp_pack(const nerf_mlp_dims* dims, const float* const* weig
                            n2_true, k_true, KT, NS, NS2, b);
         b += total;
     };
-    for (int i = 0; i < 11; ++i) NERF_REQUIRE(weights[i] != nullptr);
+    const bool view = d.V > 0;
+    const int n_head = d.sar ? 5 : 3;
+    for (int i = 0; i < 11; ++i) NERF_REQUIRE(weights[i] != nullptr || (!view && (i == 8 || i == 10)));
     pf(weights[0], d.D, d.H, 0, 0, d.D, d.DKS, d.HT);
     for (int i = 1; i < 4; ++i) pf(weights[i], d.H, d.H, d.H, HKS, 0, 0, d.HT);
     pf(weights[4], d.H + d.D, d.H, d.H, HKS, d.D, d.DKS, d.HT);
     for (int i = 5; i < 8; ++i) pf(weights[i], d.H, d.H, d.H, HKS, 0, 0, d.HT);
-    pf(weights[9], d.H, 1, d.H, HKS, 0, 0, 1);                      // density head: one tile, row 0
-    pf(weights[8], d.H + d.V, d.W, d.H, HKS, d.V, d.VKS, d.WT);     // folded colour layer
-    pf(weights[10], d.W, d.sar ? 5 : 3, d.W, 2 * d.WT, 0, 0, 1);    // rgb (+angle) heads: one tile, rows 0..4
+    pf(weights[9], d.H, view ? 1 : 1 + n_head, d.H, HKS, 0, 0, 1);  // density head: one tile, row 0 (+ the other heads)
+    if (view) {
+        pf(weights[8], d.H + d.V, d.W, d.H, HKS, d.V, d.VKS, d.WT);     // folded colour layer
+        pf(weights[10], d.W, n_head, d.W, 2 * d.WT, 0, 0, 1);           // rgb (+angle) heads: one tile, rows 0..4
+    }
     if (wbwd != nullptr) {
         // consumption order of the backward chain: heads, colour layer, 7, ..., 1 (layer 0 needs no input gradient)
-        pb(weights[10], d.W, d.sar ? 5 : 3, d.W, d.WT, 1);               // heads^T: dX9 = Wh^T dZ, one k-step
-        // [folded colour layer (its X7 columns) ; density head]^T
-        pb2(weights[8], d.H + d.V, d.W, weights[9], d.H, 1, d.H, d.HT, 2 * d.WT, 1);
+        if (view) {
+            pb(weights[10], d.W, n_head, d.W, d.WT, 1);                      // heads^T: dX9 = Wh^T dZ, one k-step
+            // [folded colour layer (its X7 columns) ; density head]^T
+            pb2(weights[8], d.H + d.V, d.W, weights[9], d.H, 1, d.H, d.HT, 2 * d.WT, 1);
+        } else {
+            pb(weights[9], d.H, 1 + n_head, d.H, d.HT, 1);                   // head tile^T: dX7 = Whd^T dZ, one k-step
+        }
         for (int i = 7; i >= 5; --i) pb(weights[i], d.H, d.H, d.H, d.HT, HKS);
         pb(weights[4], d.H + d.D, d.H, d.H, d.HT, HKS);
         for (int i = 3; i >= 1; --i) pb(weights[i], d.H, d.H, d.H, d.HT, HKS);
@@ -1447,7 +1552,7 @@ extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const f
                             float* raw_rgb, float* raw_angle, float* ln_stats, void* stream) {
     if (n_samples == 0) return NERF_OK;
     HostDims d;
-    NERF_REQUIRE(make_dims(dims, &d) && wfwd && consts && enc_frag && view_frag && raw_density && raw_rgb);
+    NERF_REQUIRE(make_dims(dims, &d) && wfwd && consts && enc_frag && (view_frag || d.V == 0) && raw_density && raw_rgb);
     NERF_REQUIRE(n_samples > 0 && ray_div > 0 && n_rays > 0);
     NERF_REQUIRE(tfrag_fmt == NERF_TFRAG_BF16 || tfrag_fmt == NERF_TFRAG_E4M3);
     if (d.sar) NERF_REQUIRE(raw_angle != nullptr);
@@ -1468,7 +1573,8 @@ extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const f
     a.t_enc = acts ? (bf16x8*)acts[20] : nullptr;
     a.t_view = acts ? (bf16x8*)acts[21] : nullptr;
     a.x7_frag = (acts && d.sar) ? (bf16x8*)acts[22] : nullptr;
-    if (acts) for (int i = 0; i < 22; ++i) NERF_REQUIRE(acts[i] != nullptr || i == 8 || i == 18);
+    // (without view directions there is no X9 either: 9, 19 and 21 unused)
+    if (acts) for (int i = 0; i < 22; ++i) NERF_REQUIRE(acts[i] != nullptr || i == 8 || i == 18 || (d.V == 0 && (i == 9 || i == 19 || i == 21)));
     if (acts && d.sar) NERF_REQUIRE(acts[22] != nullptr);
     a.raw_density = raw_density;
     a.raw_rgb = raw_rgb;
@@ -1482,15 +1588,6 @@ extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const f
     NERF_NET_LIST(X)
 #undef X
     return NERF_ERR_SIZE;
-}
-
-template <class N>
-static int launch_bwd(const MlpBwdArgs& a, hipStream_t st) {
-    static std::atomic<unsigned long long> done{0};
-    constexpr int lds = N::BWD_LDS;
-    if (!allow_dynamic_lds((const void*)mlp_bwd_kernel<N>, lds, done)) return NERF_ERR_LAUNCH;
-    hipLaunchKernelGGL((mlp_bwd_kernel<N>), dim3((unsigned)(a.nblk / 4)), dim3(64 * kWaves), lds, st, a);
-    return nerf_launch_status();
 }
 
 extern "C" int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, const float* consts, int64_t n_samples,
@@ -1513,17 +1610,17 @@ extern "C" int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, const f
     a.raw_density = raw_density; a.consts = consts;
     a.x7_frag = d.sar ? (const bf16x8*)acts[22] : nullptr;
     for (int i = 0; i < 10; ++i) {
-        NERF_REQUIRE((acts[10 + i] && dys[i]) || i == 8);
+        NERF_REQUIRE((acts[10 + i] && dys[i]) || i == 8 || (i == 9 && d.V == 0));
         a.mask[i] = (const unsigned*)acts[10 + i];
         a.tdy[i] = (bf16x8*)dys[i];
     }
-    NERF_REQUIRE(dys[10] && dys[11]);
+    NERF_REQUIRE((dys[10] || d.V == 0) && dys[11]);
     NERF_REQUIRE(tfrag_fmt == NERF_TFRAG_BF16 || tfrag_fmt == NERF_TFRAG_E4M3);
     a.tdy_hd = (bf16x8*)dys[10];
     a.tdy_dens = (bf16x8*)dys[11];
     for (int i = 0; i < 12; ++i) {
         a.tsc[i] = tfrag_fmt == NERF_TFRAG_E4M3 ? dys[12 + i] : nullptr;
-        if (tfrag_fmt == NERF_TFRAG_E4M3) NERF_REQUIRE(a.tsc[i] != nullptr || i == 8);
+        if (tfrag_fmt == NERF_TFRAG_E4M3) NERF_REQUIRE(a.tsc[i] != nullptr || i == 8 || (d.V == 0 && (i == 9 || i == 10)));
     }
 #define X(ht_, wt_, dks_, vks_, sar_)                                                            \
     if (d.HT == ht_ && d.WT == wt_ && d.DKS == dks_ && d.VKS == vks_ && (d.sar != 0) == sar_)     \
@@ -1535,6 +1632,9 @@ extern "C" int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, const f
     return NERF_ERR_SIZE;
 }
 
+#endif  // part 0
+
+#if NERF_PART_IS(7)
 // Split the NT x KT output tiles over the 4 waves (WN x WK) so that the per-wave block fits an instantiated
 // template (tn x tk accumulator tiles) with the fewest tiles.
 static bool wgrad_config(int NT, int KT, int* NW, int* WN, int* WK, int* tn, int* tk) {
@@ -1655,3 +1755,4 @@ extern "C" int nerf_mlp_wgrad(const void* dy_tfrag, int n_feat, const void* x_tf
     d.gb[0] = gb;
     return nerf_mlp_wgrad_multi(&d, n_samples, grid_hint, stream);
 }
+#endif  // part 7

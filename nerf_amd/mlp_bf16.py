@@ -56,11 +56,13 @@ class Packed:
     def __init__(self, model, need_bwd=True):
         cfg = model.config
         p = {k: v.detach() for k, v in model.named_parameters()}
-        dev = p['rgb_net0.0.weight'].device
+        dev = p['density_net0.0.weight'].device
         self.sar = 'final_angle.0.weight' in p
-        H, W = cfg.hidden, cfg.num_samples
+        # without view directions (model.py:78-92, 283-302) there is no colour layer: width and view size 0
+        self.view = 'rgb_net0.0.weight' in p
+        H, W = cfg.hidden, (cfg.num_samples if self.view else 0)
         D = 6 * (cfg.max_deg - cfg.min_deg)
-        V = 3 + 6 * (cfg.viewdirs_max_deg - cfg.viewdirs_min_deg)
+        V = 3 + 6 * (cfg.viewdirs_max_deg - cfg.viewdirs_min_deg) if self.view else 0
         self.dims = MlpDims(D, V, H, W, int(self.sar))
         self.fmt = TFRAG_FORMATS[getattr(cfg, 'wgrad_operands', None) or DEFAULT_WGRAD_OPERANDS]
         self.H, self.W, self.D, self.V = H, W, D, V
@@ -84,15 +86,20 @@ class Packed:
             self.head_density = wd.contiguous()
             self.head_colour = p['final_rgb.0.weight'].contiguous()
             head_bias = p['final_rgb.0.bias']
-        # rgb_net0 (no activation, model.py:82-84) folded into rgb_net1: one matrix on [trunk output | view features]
-        self.W8, self.b8 = f32c(p['rgb_net0.0.weight']), f32c(p['rgb_net0.0.bias'])
-        self.W9 = f32c(p['rgb_net1.0.weight'])
-        fold = self.W9.clone()
-        fold[:, :H] = gemm(self.W9, (H + V, 1), self.W8, (H, 1), W, H, H)                        # W9[:, :H] @ W8
-        bias9 = gemm(self.b8, (H, 1), self.W9, (1, H + V), 1, W, H, bias=f32c(p['rgb_net1.0.bias']))[0]  # b8 W9a^T + b9
-        mats = [f32c(p[n + '.weight']) for n in STREAMED[:8]] + [fold, f32c(self.head_density), f32c(self.head_colour)]
+        if self.view:
+            # rgb_net0 (no activation, model.py:82-84) folded into rgb_net1: one matrix on [trunk output | view features]
+            self.W8, self.b8 = f32c(p['rgb_net0.0.weight']), f32c(p['rgb_net0.0.bias'])
+            self.W9 = f32c(p['rgb_net1.0.weight'])
+            fold = self.W9.clone()
+            fold[:, :H] = gemm(self.W9, (H + V, 1), self.W8, (H, 1), W, H, H)                        # W9[:, :H] @ W8
+            bias9 = gemm(self.b8, (H, 1), self.W9, (1, H + V), 1, W, H, bias=f32c(p['rgb_net1.0.bias']))[0]  # b8 W9a^T + b9
+            tail = [fold, f32c(self.head_density), f32c(self.head_colour)]
+        else:
+            # one head tile on the trunk output: density row, then the colour (and angle) heads
+            tail = [None, torch.cat([self.head_density, self.head_colour], 0).contiguous(), None]
+        mats = [f32c(p[n + '.weight']) for n in STREAMED[:8]] + tail
         self._keep = mats
-        arr = (c_void_p * 11)(*[m.data_ptr() for m in mats])
+        arr = (c_void_p * 11)(*[m.data_ptr() if m is not None else None for m in mats])
         check(lib().nerf_mlp_pack(ctypes.byref(self.dims), arr, _raw(self.wfwd),
                                   _raw(self.wbwd) if need_bwd else None, stream()))
 
@@ -101,12 +108,16 @@ class Packed:
         for i, n in enumerate(STREAMED[:8]):
             c[i * HP:i * HP + H] = p[n + '.bias']
         o = 8 * HP
-        c[o:o + W] = bias9
+        if self.view:
+            c[o:o + W] = bias9
         o += WP
         if not self.sar:
             c[o] = bd[0]
+        if not self.view:
+            c[o + 1:o + 1 + head_bias.numel()] = head_bias
         o += 32
-        c[o:o + head_bias.numel()] = head_bias
+        if self.view:
+            c[o:o + head_bias.numel()] = head_bias
         o += 32
         if self.sar:
             c[o + 6] = self.head_density.sum()
@@ -117,7 +128,10 @@ class Packed:
         # algorithmic work per sample (true layer sizes): forward MACs, input-gradient MACs (no gradient
         # w.r.t. the encodings), weight-gradient MACs; bytes = bf16 operands the weight-gradient pass must read
         heads = 1 + (5 if self.sar else 3)
-        macs_fwd = D * H + 3 * H * H + (H + D) * H + 3 * H * H + H + H * H + (H + V) * W + (heads - 1) * W
+        if self.view:
+            macs_fwd = D * H + 3 * H * H + (H + D) * H + 3 * H * H + H + H * H + (H + V) * W + (heads - 1) * W
+        else:
+            macs_fwd = D * H + 3 * H * H + (H + D) * H + 3 * H * H + heads * H
         macs_dx = macs_fwd - D * H - D * H - V * W
         self.fwd_flops = 2.0 * macs_fwd
         self.bwd_dx_flops = 2.0 * macs_dx
@@ -146,6 +160,10 @@ def _wgrad_plan(pk):
     # in one launch.  dY9^T X7 lands in the scratch pair '_g98' (fold_gradients turns it into the gradients of
     # rgb_net0.0 and of the trunk columns of rgb_net1.0); dY9^T view is the gradient of rgb_net1.0's view columns.
     # (SAR: the density tile carries rows g*rstd, g*rstd*mean, g; they land in the scratch pair '_dens')
+    if not pk.view:
+        # one head tile on the trunk output, rows: density, rgb 1..3 (SAR: angle 4..5, and the LayerNorm sums
+        # g*rstd*mean, g in rows 6..7: only their column sums are used); lands in the scratch pair '_hd'
+        return plan + [one(11, 32, 8 if pk.sar else 4, '_hd', ('x', 7), HP, H)]
     dens = ('_dens', 3) if pk.sar else ('final_density.0', 1)
     plan += [([(9, WP, W, '_g98'), (11, 32, dens[1], dens[0])], [(('x', 7), HP, H), ('view', VP, V)],
               [[('_g98', 0), ('rgb_net1.0', H)], [(dens[0], 0), None]])]
@@ -208,9 +226,10 @@ def act_block_bytes(pk):
     """Bytes per block of 64 samples of each buffer the forward chain saves (index as in `acts`; None = unused)."""
     tiles = [pk.HT] * 9 + [pk.WT]
     piece = 4096 >> pk.fmt                          # transposed fragments: bf16 or e4m3
-    per = [t * piece if i != 8 else None for i, t in enumerate(tiles)]
-    per += [2 * ((t + 1) // 2) * 256 if i != 8 else None for i, t in enumerate(tiles)]
-    per += [pk.DT * piece, pk.VT * piece]
+    used = lambda i, t: i != 8 and t > 0            # (no X8 since the fold; no X9 without view directions)
+    per = [t * piece if used(i, t) else None for i, t in enumerate(tiles)]
+    per += [2 * ((t + 1) // 2) * 256 if used(i, t) else None for i, t in enumerate(tiles)]
+    per += [pk.DT * piece, pk.VT * piece if pk.view else None]
     if pk.sar:
         per.append(32 * pk.HT * 128)
     return per
@@ -219,9 +238,10 @@ def act_block_bytes(pk):
 def dy_block_bytes(pk):
     """Bytes per block of 64 samples of each dY buffer of the backward chain (None = unused); in the e4m3 format 12
     more entries: the scale bytes of each (8 bytes per feature row and 32-sample block)."""
-    per = [t * (4096 >> pk.fmt) if i != 8 else None for i, t in enumerate([pk.HT] * 9 + [pk.WT, 1, 1])]
+    tiles = [pk.HT] * 9 + [pk.WT, 1 if pk.view else 0, 1]
+    per = [t * (4096 >> pk.fmt) if (i != 8 and t > 0) else None for i, t in enumerate(tiles)]
     if pk.fmt:
-        per += [512 if i != 8 else None for i in range(12)]
+        per += [512 if b is not None else None for b in per[:12]]
     return per
 
 
@@ -245,7 +265,7 @@ def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False, acts=None
         arr = (c_void_p * len(acts))(*[a.data_ptr() if a is not None else None for a in acts])
     saved = sum(a.numel() for a in acts if a is not None) if acts is not None else 0   # bytes the launch writes for the backward pass
     with profiling.timed('mlp_fwd_kernel', flops=pk.fwd_flops * n_samples, bytes_=float(saved)):
-        check(lib().nerf_mlp_fwd(ctypes.byref(pk.dims), _raw(pk.wfwd), ptr(pk.consts), _raw(enc), _raw(view),
+        check(lib().nerf_mlp_fwd(ctypes.byref(pk.dims), _raw(pk.wfwd), ptr(pk.consts), _raw(enc), _raw(view) if pk.view else None,
                                  n_samples, ray_div, n_rays, arr, pk.fmt, ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
                                  ptr(ln_stats), stream()))
     return raw_density, raw_rgb, raw_angle, acts, ln_stats
@@ -318,6 +338,21 @@ def mlp_weight_grads(pk, acts, dys, n_samples, grads):
     """Accumulate all weight / bias gradients into `grads` (name -> zero-initialised or running fp32 tensor)."""
     dev = pk.consts.device
     grads = dict(grads)
+    if not pk.view:
+        hd_w, hd_b = torch.zeros(8, pk.H, device=dev), torch.zeros(8, device=dev)
+        grads['_hd.weight'], grads['_hd.bias'] = hd_w, hd_b
+        _wgrad_launches(pk, acts, dys, n_samples, grads)
+        if pk.sar:      # (the caller assembles the LayerNorm / density gradients from these, see _MlpSar)
+            grads['_dens.weight'][0].add_(hd_w[0])
+            grads['_dens.bias'][1:3].add_(hd_b[6:8])
+            grads['_heads.weight'].add_(hd_w[1:6])
+            grads['_heads.bias'].add_(hd_b[1:6])
+        else:
+            grads['final_density.0.weight'].add_(hd_w[0:1])
+            grads['final_density.0.bias'].add_(hd_b[0:1])
+            grads['final_rgb.0.weight'].add_(hd_w[1:4])
+            grads['final_rgb.0.bias'].add_(hd_b[1:4])
+        return
     grads['_g98.weight'], grads['_g98.bias'] = torch.zeros(pk.W, pk.H, device=dev), torch.zeros(pk.W, device=dev)
     _wgrad_launches(pk, acts, dys, n_samples, grads)
     fold_gradients(pk, grads)
@@ -353,6 +388,11 @@ def _wgrad_launches(pk, acts, dys, n_samples, grads):
 
 PARAM_NAMES = [n + s for n in STREAMED + ['final_density.0', 'final_rgb.0'] for s in ('.weight', '.bias')]
 
+
+def _present(names, params):
+    """The names the model has (without view directions there is no rgb_net0 / rgb_net1, model.py:79-89)."""
+    return [k for k in names if k in params]
+
 _ACCUMULATE_INTO_GRAD = False
 
 
@@ -383,6 +423,7 @@ class _MlpNerf(torch.autograd.Function):
         ctx.pk, ctx.acts, ctx.n = pk, acts, n_samples
         ctx.shapes = [(p.shape, p.device) for p in params]
         ctx.params = params
+        ctx.names = _present(PARAM_NAMES, dict(model.named_parameters()))
         ctx.save_for_backward(rgb)
         return d.reshape(-1, 1), rgb
 
@@ -393,15 +434,16 @@ class _MlpNerf(torch.autograd.Function):
         dys = mlp_backward(pk, ctx.acts, ctx.n, g_density, g_rgb, rgb)
         in_place = _ACCUMULATE_INTO_GRAD and all(
             q.grad is not None and q.grad.dtype == torch.float32 and q.grad.is_contiguous() for q in ctx.params)
+        names = ctx.names
         if in_place:
-            grads = {n: q.grad for n, q in zip(PARAM_NAMES, ctx.params)}
+            grads = {n: q.grad for n, q in zip(names, ctx.params)}
         else:
-            grads = {n: torch.zeros(shape, device=dev, dtype=torch.float32) for n, (shape, dev) in zip(PARAM_NAMES, ctx.shapes)}
+            grads = {n: torch.zeros(shape, device=dev, dtype=torch.float32) for n, (shape, dev) in zip(names, ctx.shapes)}
         mlp_weight_grads(pk, ctx.acts, dys, ctx.n, grads)
         ctx.acts = ctx.params = None
         if in_place:
-            return (None,) * (6 + len(PARAM_NAMES))
-        return (None, None, None, None, None, None) + tuple(grads[n] for n in PARAM_NAMES)
+            return (None,) * (6 + len(names))
+        return (None, None, None, None, None, None) + tuple(grads[n] for n in names)
 
 
 def query_nerf(model, t_vals, rays, viewf, S):
@@ -410,7 +452,7 @@ def query_nerf(model, t_vals, rays, viewf, S):
     n = t_vals.shape[0]
     encf = encode_frag(t_vals, rays.origins, rays.directions, rays.radii, model.ray_shape, cfg.min_deg, cfg.max_deg)
     p = dict(model.named_parameters())
-    params = [p[k] for k in PARAM_NAMES]
+    params = [p[k] for k in _present(PARAM_NAMES, p)]
     if not (torch.is_grad_enabled() and any(q.requires_grad for q in params)):      # inference: nothing saved
         d, rgb, _, _, _ = mlp_forward(packed_for(model, need_bwd=False), encf, viewf, n * S, S, n, save=False)
         return d.reshape(-1, 1), rgb
@@ -432,7 +474,8 @@ class _MlpSar(torch.autograd.Function):
         pk = packed_for(model, need_bwd=need_grad)
         d, rgb, ang, acts, ln = mlp_forward(pk, encf, viewf, n_samples, ray_div, n_rays, save=need_grad)
         ctx.pk, ctx.acts, ctx.n = pk, acts, n_samples
-        ctx.params = {n: p.detach() for n, p in zip(SAR_PARAM_NAMES, params)}
+        ctx.names = _present(SAR_PARAM_NAMES, dict(model.named_parameters()))
+        ctx.params = {n: p.detach() for n, p in zip(ctx.names, params)}
         ctx.save_for_backward(d, rgb, ang, ln)
         return d.reshape(-1, 1), rgb, ang
 
@@ -442,9 +485,10 @@ class _MlpSar(torch.autograd.Function):
         pk, P = ctx.pk, ctx.params
         dys = mlp_backward(pk, ctx.acts, ctx.n, g_density, g_rgb, rgb, g_angle, d, ang, ln)
         dev = d.device
-        grads = {n: torch.zeros_like(P[n]) for n in SAR_PARAM_NAMES}
+        grads = {n: torch.zeros_like(P[n]) for n in ctx.names}
         grads['_dens.weight'], grads['_dens.bias'] = torch.zeros(3, pk.H, device=dev), torch.zeros(3, device=dev)
-        grads['_heads.weight'], grads['_heads.bias'] = torch.zeros(5, pk.W, device=dev), torch.zeros(5, device=dev)
+        grads['_heads.weight'] = torch.zeros(5, pk.W if pk.view else pk.H, device=dev)       # the heads' input width
+        grads['_heads.bias'] = torch.zeros(5, device=dev)
         mlp_weight_grads(pk, ctx.acts, dys, ctx.n, grads)
         ctx.acts = None
         # d = sum_f w_f (gamma_f xhat_f + beta_f) + b, xhat = (x - mean) rstd:
@@ -459,7 +503,7 @@ class _MlpSar(torch.autograd.Function):
         grads['final_density.0.bias'] = w * sg
         grads['final_rgb.0.weight'], grads['final_rgb.0.bias'] = grads['_heads.weight'][:3], grads['_heads.bias'][:3]
         grads['final_angle.0.weight'], grads['final_angle.0.bias'] = grads['_heads.weight'][3:], grads['_heads.bias'][3:]
-        return (None, None, None, None, None, None) + tuple(grads[n] for n in SAR_PARAM_NAMES)
+        return (None, None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
 
 
 def query_sar(model, t_vals, origins, ray_d, radii, viewf, R, S):
@@ -468,7 +512,7 @@ def query_sar(model, t_vals, origins, ray_d, radii, viewf, R, S):
     cfg = model.config
     encf = encode_frag(t_vals, origins, ray_d, radii, model.ray_shape, cfg.min_deg, cfg.max_deg)
     p = dict(model.named_parameters())
-    params = [p[k] for k in SAR_PARAM_NAMES]
+    params = [p[k] for k in _present(SAR_PARAM_NAMES, p)]
     if not (torch.is_grad_enabled() and any(q.requires_grad for q in params)):      # inference: nothing saved
         d, rgb, ang, _, _ = mlp_forward(packed_for(model, need_bwd=False), encf, viewf, R * S, R, R, save=False)
         return d.reshape(-1, 1), rgb, ang

@@ -158,9 +158,6 @@ class MipNeRF(_RenderModule):
             self.rgb_net0 = nn.Sequential(nn.Linear(config.hidden, config.hidden))
             self.viewdirs_encoding = PositionalEncoding(config.viewdirs_min_deg, config.viewdirs_max_deg)
             self.rgb_net1 = nn.Sequential(nn.Linear(config.hidden + self.rgb_input, config.num_samples), nn.ReLU(True))
-        elif getattr(config, 'mlp_precision', 'fp32') == 'bf16':
-            raise NotImplementedError("the fused bf16 chain implements the view-dependent network; with "
-                                      "use_viewdirs=False use mlp_precision='fp32'")
         self.final_rgb = nn.Sequential(nn.Linear(input_shape, 3), nn.Sigmoid())
         _xavier_init(self)
         self._packed = None
@@ -295,9 +292,6 @@ class SARNeRF(_RenderModule):
             self.rgb_net0 = nn.Sequential(nn.Linear(config.hidden, config.hidden))
             self.viewdirs_encoding = PositionalEncoding(config.viewdirs_min_deg, config.viewdirs_max_deg)
             self.rgb_net1 = nn.Sequential(nn.Linear(config.hidden + self.rgb_input, config.num_samples), nn.ReLU(True))
-        elif getattr(config, 'mlp_precision', 'fp32') == 'bf16':
-            raise NotImplementedError("the fused bf16 chain implements the view-dependent network; with "
-                                      "use_viewdirs=False use mlp_precision='fp32'")
         self.final_rgb = nn.Sequential(nn.Linear(input_shape, 3), nn.Sigmoid())
         self.final_angle = nn.Sequential(nn.Linear(input_shape, 2), nn.Sigmoid())
         _xavier_init(self)
@@ -351,10 +345,11 @@ class SARNeRF(_RenderModule):
                 continue                        # every rank walks the same CPU generator sequence)
             ray_d, ray_p = ops.sar_raygen(az.to(dev), el.to(dev))
             bf16 = self._precision() == 'bf16'
+            if bf16:
+                from . import mlp_bf16
             if not self.use_viewdirs:
                 view_feat = None
             elif bf16:
-                from . import mlp_bf16
                 view_feat = mlp_bf16.view_frag(ray_d, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg)
             else:
                 view_feat = ops.pe_encode(ray_d, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg, append_input=True)

@@ -26,10 +26,10 @@ _EPS32 = float(torch.finfo(torch.float32).eps)
 
 
 def supported(model):
-    """The fused step covers the view-dependent bf16 network without density noise (model.py:135-136 draws noise
-    between the MLP and the compositing; that variant goes through autograd)."""
+    """The fused step covers the bf16 network without density noise (model.py:135-136 draws noise between the MLP
+    and the compositing; that variant goes through autograd)."""
     cfg = model.config
-    return (getattr(cfg, 'mlp_precision', 'fp32') == 'bf16' and model.use_viewdirs
+    return (getattr(cfg, 'mlp_precision', 'fp32') == 'bf16'
             and not (model.randomized and model.density_noise) and not getattr(model, 'return_raw', False)
             and hasattr(model, 'white_bkgd'))
 
@@ -60,7 +60,7 @@ class NerfStepper:
         self.g_density, self.g_rgb = torch.zeros(m_all, device=dev), torch.zeros(m_all, 3, device=dev)
         dks = pk.DKS
         self.enc = [u8(nb * dks * 2 * 1024) for nb in self.nblk]
-        self.view = u8(n * pk.VKS * 2 * 16)
+        self.view = u8(n * pk.VKS * 2 * 16) if pk.view else None
         self.t_vals = [f32(n, S + 1) for S in self.levels]
         self.rand = [f32(n, S + 1) for S in self.levels]
         self.weights = [f32(n, S) for S in self.levels]
@@ -95,7 +95,8 @@ class NerfStepper:
         if global_mask_sum is None:
             global_mask_sum = lossmult.sum()
         torch.reciprocal(torch.as_tensor(global_mask_sum, dtype=torch.float32, device=dev).reshape(1), out=self.inv_mask_sum)
-        check(L_.nerf_view_frag(ptr(vd), n, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg, c_void_p(self.view.data_ptr()), st))
+        if pk.view:
+            check(L_.nerf_view_frag(ptr(vd), n, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg, c_void_p(self.view.data_ptr()), st))
         act = ctypes.byref(NerfActivation(1, float(model.rgb_padding), float(model.density_bias)))
         cwd = float(model.loss_function.coarse_weight_decay)
         nl = len(self.levels)

@@ -11,7 +11,10 @@ pytestmark = pytest.mark.gpu
 
 SAR_CASES = [('small_metres', dict(hidden=64, num_samples=32, max_deg=4), 32, 128, True),
              ('small', dict(hidden=64, num_samples=32, max_deg=4), 32, 96, False),
-             ('c4', dict(hidden=156, num_samples=180, max_deg=4), 180, 24, False)]
+             ('c4', dict(hidden=156, num_samples=180, max_deg=4), 180, 24, False),
+             # use_viewdirs=False (model.py:283-302): density, rgb and angle heads all on the trunk output
+             ('small_noview', dict(hidden=64, num_samples=32, max_deg=4, use_viewdirs=False), 32, 96, False),
+             ('c4_noview', dict(hidden=156, num_samples=180, max_deg=4, use_viewdirs=False), 180, 24, False)]
 
 
 def sar_inputs(cfg, S, R, seed=3, metres=True):
@@ -46,13 +49,13 @@ def test_sar_mlp_forward_vs_oracle(tag, kw, S, R, metres):
     origins, ray_d, ray_p, radii, t = sar_inputs(cfg, S, R, metres=metres)
     mean, cov = O.cast_rays(t, origins, ray_d, radii, 'cone')
     enc = O.ipe(mean, cov, cfg.min_deg, cfg.max_deg).reshape(R * S, -1)
-    rows = O.sar_view_rows(ray_d, S, cfg)                    # row i takes ray i mod R (model.py:351-354)
+    rows = O.sar_view_rows(ray_d, S, cfg) if cfg.use_viewdirs else None      # row i takes ray i mod R (model.py:351-354)
     ref_d, ref_rgb, ref_ang = O.mlp_sar(p, enc, rows)
 
     pk = mlp_bf16.packed_for(m, need_bwd=False)
-    assert pk.sar
+    assert pk.sar and pk.view == cfg.use_viewdirs
     encf = mlp_bf16.encode_frag(t.cuda(), origins.cuda(), ray_d.cuda(), radii.cuda(), 'cone', cfg.min_deg, cfg.max_deg)
-    viewf = mlp_bf16.view_frag(ray_d.cuda(), 0, 4)
+    viewf = mlp_bf16.view_frag(ray_d.cuda(), 0, 4) if cfg.use_viewdirs else None
     for save in (False, True):
         d, rgb, ang, acts, ln = mlp_bf16.mlp_forward(pk, encf, viewf, R * S, R, R, save=save)
         assert relerr(d.cpu(), ref_d[:, 0]) < 2e-2, (tag, save)
@@ -76,7 +79,7 @@ def test_sar_mlp_gradients(tag, kw, S, R, metres):
     origins, ray_d, ray_p, radii, t = sar_inputs(cfg, S, R, metres=metres)
     mean, cov = O.cast_rays(t, origins, ray_d, radii, 'cone')
     enc = O.ipe(mean, cov, cfg.min_deg, cfg.max_deg).reshape(R * S, -1)
-    ref = O.mlp_sar(p, enc, O.sar_view_rows(ray_d, S, cfg))
+    ref = O.mlp_sar(p, enc, O.sar_view_rows(ray_d, S, cfg) if cfg.use_viewdirs else None)
     g = torch.Generator().manual_seed(9)
     # smooth upstream gradients: low-frequency functions of the sample index, not white noise (white noise makes
     # every ReLU flip of the bf16 forward visible and says nothing about the kernels)
@@ -84,7 +87,7 @@ def test_sar_mlp_gradients(tag, kw, S, R, metres):
     ups = [torch.cos(3 * x + i) * (0.5 + torch.rand(1, c, generator=g)) for i, c in enumerate((1, 3, 2))]
     sum((o * u).sum() for o, u in zip(ref, ups)).backward()
 
-    viewf = mlp_bf16.view_frag(ray_d.cuda(), 0, 4)
+    viewf = mlp_bf16.view_frag(ray_d.cuda(), 0, 4) if cfg.use_viewdirs else None
     out = mlp_bf16.query_sar(m, t.cuda(), origins.cuda(), ray_d.cuda(), radii.cuda(), viewf, R, S)
     sum((o * u.cuda()).sum() for o, u in zip(out, ups)).backward()
     worst, cos = {}, {}
@@ -105,11 +108,12 @@ def test_sar_mlp_gradients(tag, kw, S, R, metres):
         assert worst[k] < 3e-2, (k, worst[k])
 
 
-def test_sar_end_to_end_bf16(golden):
+@pytest.mark.parametrize('tag', ['rand', 'det_noview'])
+def test_sar_end_to_end_bf16(golden, tag):
     """SARNeRF.forward on the bf16 chain against the oracle at a long wavelength (well-conditioned fp32 phase):
     pulses, distance, acc and the loss within the bf16 gate; gradients finite and aligned with the oracle's."""
     from tests.conftest import T, cfg_from
-    fx = golden('sar_e2e_rand')
+    fx = golden('sar_e2e_' + tag)
     cfg = cfg_from(fx)
     cfg.wavelength = 40.0
     cfg.mlp_precision = 'bf16'
@@ -119,13 +123,14 @@ def test_sar_end_to_end_bf16(golden):
     m.load_state_dict({k: v.detach() for k, v in p.items()}, strict=False)
     chunks = cfg.total_num_rays // cfg.rays_per_chunk
     az_el = [(T(fx[f'az_{c}']), T(fx[f'el_{c}'])) for c in range(chunks)]
-    t_rand = [T(fx[f't_rand_{c}']) for c in range(chunks)]
-    u_rand = [T(fx[f'u_rand_{c}']) for c in range(chunks)]
+    t_rand = [T(fx[f't_rand_{c}']) for c in range(chunks)] if cfg.randomized else None
+    u_rand = [T(fx[f'u_rand_{c}']) for c in range(chunks)] if cfg.randomized else None
     mfilt = torch.complex(T(fx['mfilt_re']), T(fx['mfilt_im']))
     nsam = int(fx['nsam'])
     ref_p, ref_d, ref_a, _ = O.sar_render(p, T(fx['ray_o']), az_el, mfilt, float(fx['radii'][0]), float(fx['near'][0]),
-                                          float(fx['far'][0]), nsam, float(fx['mpp'][0]), cfg, t_rand, [{1: u} for u in u_rand])
-    cu = lambda xs: [x.cuda() for x in xs]
+                                          float(fx['far'][0]), nsam, float(fx['mpp'][0]), cfg, t_rand,
+                                          [{1: u} for u in u_rand] if u_rand is not None else None)
+    cu = lambda xs: None if xs is None else [x.cuda() for x in xs]
     got_p, got_d, got_a = m(T(fx['ray_o']), None, None, mfilt, T(fx['radii']), T(fx['near']), T(fx['far']), nsam,
                             T(fx['mpp']), az_el=az_el, t_rand=cu(t_rand), u_rand=cu(u_rand))
     assert relerr(got_a.cpu(), ref_a) < 2e-2
