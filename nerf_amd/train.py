@@ -83,9 +83,12 @@ def allreduce_grads(params, world_size):
 
 
 def _all_reduce_sum(t, async_op=False):
-    """In-place SUM all-reduce.  RCCL reduces device buffers directly; under gloo (CPU rehearsals of the multi-rank
-    path) a device tensor is staged through host memory: gloo's own device path was seen to hang on a 2.4 MB
-    bucket with two ranks on one GPU."""
+    """In-place SUM all-reduce.  RCCL reduces device buffers directly; under gloo (rehearsals of the multi-rank
+    path with both ranks on one GPU) a device tensor is staged through host memory, because gloo's own device path
+    blocks there: `tools/diag_gloo_device.py` shows `dist.all_reduce` on a CUDA tensor completing on an idle device
+    and never returning (both ranks, already for 1 KiB) as soon as kernels are still queued on the tensor's stream
+    when the collective is called -- the hand-over from the compute stream to gloo's copy stream does not resolve
+    on this ROCm build; size does not matter.  `.cpu()` waits for the stream first, so the staged form is safe."""
     import torch.distributed as dist
     if t.is_cuda and dist.get_backend() == 'gloo':
         host = t.cpu()
