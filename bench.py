@@ -173,6 +173,9 @@ def main():
     ap.add_argument('--rehearse-one-gpu', action='store_true',
                     help='N>1 ranks all on cuda:0 over gloo: a rehearsal of the multi-rank code path on a one-GPU box '
                          '(its numbers mean nothing)')
+    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
+                    help='c4 only: replay the pulse step as one captured HIP graph (auto: on for one rank; per-kernel '
+                         'timings are then not collected)')
     ap.add_argument('--workload', default='c3', choices=['c3', 'c2', 'c4'],
                     help="c3 (default, the headline metric): full train step; c2: forward-only render (use --rays 1048576); "
                          "c4: SAR-NeRF pulse step at the reference's params.yaml sizes (2048 rays x 180+180 samples)")
@@ -205,6 +208,7 @@ def main():
 
     torch.manual_seed(0)
     sar = args.workload == 'c4'
+    graphed = False
     cfg = make_sar_cfg(args.precision) if sar else make_cfg(args.precision)
     cfg.wgrad_operands = args.wgrad_operands
     model = (SARNeRF(cfg) if sar else MipNeRF(cfg)).to(dev).train()
@@ -216,8 +220,14 @@ def main():
         # one pulse per step and rank (ranks take different pulses: weak scaling); the reference's lr_init of 0.5
         # diverges on synthetic targets within a few steps, so the timed steps use a small fixed rate
         args.rays = cfg.total_num_rays
-        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=cfg.weight_decay, fused=True)
+        graphed = args.graph == 'on' or (args.graph == 'auto' and world == 1)
+        if graphed and world > 1:
+            raise SystemExit('--graph on needs one rank (the captured step holds no collective)')
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=cfg.weight_decay, fused=True, capturable=graphed)
         batch = sar_batch(dev, seed=100 + rank)
+        if graphed:
+            from nerf_amd.train import GraphedSarStep
+            gstep = GraphedSarStep(model, batch, opt)
     else:
         opt = torch.optim.AdamW(params, lr=cfg.lr_init, weight_decay=cfg.weight_decay, fused=True)
         rays, pixels = synthetic_rays(args.rays, dev, seed=1234 + rank)
@@ -227,6 +237,8 @@ def main():
         if args.workload == 'c2':                   # coarse+fine render only, nothing saved for a backward pass
             with torch.no_grad():
                 return model(rays)[0].sum()
+        if sar and graphed:
+            return gstep.step()
         if sar:                                     # every rank renders a whole pulse of its own; gradients are averaged
             return sar_pulse_step(model, batch, opt, world)
         return nerf_train_step(model, rays, pixels, opt, chunk=args.chunk, world_size=world, global_mask_sum=mask_sum)
@@ -239,7 +251,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    profiling.enable(True)
+    profiling.enable(not (sar and graphed))         # (HIP events around single launches mean nothing inside a replay)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -270,6 +282,7 @@ def main():
                        'chunk_rays': args.chunk,
                        'wgrad_operands': args.wgrad_operands or mlp_default_operands(),
                        'parallelism': f'ray-sharded dp{world}, flat-bucket grad all-reduce',
+                       **({'hip_graph': bool(graphed)} if sar else {}),
                        'loss': float(loss)},
         }
         if prof:

@@ -122,8 +122,8 @@ class Packed:
         if self.sar:
             c[o + 6] = self.head_density.sum()
             c[o + 7] = (wd[0] * beta).sum() + bd[0]
-            c[o + 8] = 1.0 / H
-            c[o + 9] = 1e-5
+            c[o + 8:o + 9].fill_(1.0 / H)        # (fill_: a kernel argument, where item assignment of a Python
+            c[o + 9:o + 10].fill_(1e-5)          # number copies from host memory, which a graph capture refuses)
         self.consts = c
         # algorithmic work per sample (true layer sizes): forward MACs, input-gradient MACs (no gradient
         # w.r.t. the encodings), weight-gradient MACs; bytes = bf16 operands the weight-gradient pass must read

@@ -192,7 +192,7 @@ def sar_train_step(model, batch, optimizer, rank=0, world_size=1, scheduler=None
     bucket.zero()
     pulses = model(ray_o, pan, tilt, mfilt, radii, near, far, pulse_data.shape[1], mpp, rank=rank,
                    world_size=world_size, **draws)[0]
-    loss, _ = model.loss_function(pulses, pulse_data.to(pulses.device))
+    loss, _ = model.loss_function.level_losses(pulses, pulse_data.to(pulses.device))      # (the PSNRs go to the host)
     if loss.requires_grad:              # a rank that was dealt no chunk has nothing to differentiate
         loss.backward()
     bucket.attach()
@@ -202,3 +202,55 @@ def sar_train_step(model, batch, optimizer, rank=0, world_size=1, scheduler=None
         scheduler.step()
     model._weights_changed()
     return loss.detach()
+
+
+class GraphedSarStep:
+    """`sar_train_step` captured once as a HIP graph and replayed.
+
+    At the reference's sizes (params.yaml:67-93: 2048 rays x 180 samples per chunk, a 156-wide network) one pulse is
+    about a hundred short launches -- samplers, encoders, chain kernels, scatter, FFTs, loss, the backward of all of
+    them, AdamW, weight repack -- and a step issued launch by launch is bound by the host; replaying the captured
+    graph leaves only the kernels.  Needs one rank, `config.check_range = False` (the range check reads a status
+    word back, which a capture cannot do) and an optimizer built with `capturable=True`.  The beam offsets are
+    drawn on the device (the reference draws them on the host, model.py:319-320: same distribution, another
+    stream of numbers); every replay draws afresh.  The `warmup` eager runs that precede the capture are real
+    optimizer steps."""
+
+    def __init__(self, model, batch, optimizer, warmup=3):
+        if getattr(model.config, 'check_range', True):
+            raise ValueError('GraphedSarStep: set config.check_range = False (the check synchronises the stream)')
+        if not all(g.get('capturable', False) for g in optimizer.param_groups):
+            raise ValueError('GraphedSarStep: build the optimizer with capturable=True')
+        self.model, self.optimizer = model, optimizer
+        dev = model.device
+        self.batch = tuple(x.to(dev).clone() if torch.is_tensor(x) else x for x in batch)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):           # one-time work (LDS attributes, FFT plans, optimizer state) happens here
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._body()
+
+    def _body(self):
+        from .model import SAR_AZ_SIGMA, SAR_EL_SIGMA
+        m = self.model
+        az_el = [(torch.randn(m.rays_per_chunk, device=m.device) * SAR_AZ_SIGMA,
+                  torch.randn(m.rays_per_chunk, device=m.device) * SAR_EL_SIGMA) for _ in range(m.num_ray_iters)]
+        return sar_train_step(m, self.batch, self.optimizer, az_el=az_el)
+
+    def step(self, batch=None, lr=None):
+        """Replay on `batch` (copied into the captured tensors; None = the same pulse again) -> the loss tensor of
+        the capture (overwritten by every replay).  `lr` updates a tensor learning rate in place."""
+        if batch is not None:
+            for dst, src in zip(self.batch, batch):
+                if torch.is_tensor(dst):
+                    dst.copy_(src)
+        if lr is not None:
+            for g in self.optimizer.param_groups:
+                g['lr'].fill_(lr) if torch.is_tensor(g['lr']) else g.__setitem__('lr', lr)
+        self.graph.replay()
+        self.model._weights_changed()           # the packed streams outside the graph are one step behind
+        return self.loss

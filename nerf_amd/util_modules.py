@@ -79,7 +79,11 @@ class SARNeRFLoss(torch.nn.modules.loss._Loss):
         super().__init__()
         self.coarse_weight_decay = coarse_weight_decay
 
-    def forward(self, input, target):
+    def level_losses(self, input, target):
+        """-> total loss, per-level MSEs; both stay on the device (no host copy: usable under graph capture)."""
         losses = torch.stack([((x - target) ** 2).mean() for x in input])
-        loss = self.coarse_weight_decay * torch.sum(losses[:-1]) + losses[-1]
+        return self.coarse_weight_decay * torch.sum(losses[:-1]) + losses[-1], losses
+
+    def forward(self, input, target):
+        loss, losses = self.level_losses(input, target)
         return loss, mse_to_psnr(losses.detach()).cpu()
