@@ -284,6 +284,16 @@ int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* const
                  const void* view_frag, int64_t n_samples, int ray_div, int64_t n_rays, void* const* acts,
                  int tfrag_fmt, float* raw_density, float* raw_rgb, float* raw_angle, float* ln_stats, void* stream);
 
+/* nerf_mlp_fwd and nerf_composite_fwd of one level in one launch, for inference: the workgroup that evaluates 256
+ * consecutive samples composites the 256 / num_samples rays they belong to, so the raw outputs never go to HBM and
+ * the results are those of the two separate calls, bit for bit.  num_samples must divide 256 and the heads must be
+ * the NeRF ones (NERF_ERR_SIZE otherwise: use the two calls).  weights [n_rays, num_samples] is nullable (the last
+ * level needs none).                       reference: model.py:117-141 as one expression chain, utils.py:283-318 */
+int nerf_mlp_fwd_composite(const nerf_mlp_dims* dims, const void* wfwd, const float* consts, const void* enc_frag,
+                           const void* view_frag, int64_t n_rays, int num_samples, const float* t_vals,
+                           const float* dirs, int white_bkgd, const nerf_activation* act, float* comp_rgb,
+                           float* distance, float* acc, float* weights, void* stream);
+
 /* Backward chain of the fused MLP: from dL/d raw_density [M], dL/d raw_rgb [M,3] (w.r.t. the
  * post-sigmoid output; raw_rgb is that saved output) through every layer, writing dL/d(layer
  * pre-activation) as transposed bf16 fragments (feature on the lane, 16 samples per k-step:

@@ -37,6 +37,7 @@
 #include <atomic>
 
 #include "common.h"
+#include "composite_core.h"
 #include "mlp_frag.h"
 
 // This file can be compiled in parts (-DNERF_NET_PART=p, one object each) so that the chain kernels of the
@@ -247,7 +248,18 @@ struct MlpFwdArgs {
     float* raw_rgb;            // [M,3]  (post sigmoid)
     float* raw_angle;          // [M,2]  (SAR, post sigmoid)
     float* ln_stats;           // [M,2]  (SAR: mean, rstd of the trunk output) nullable
+    // fused render epilogue (inference, NeRF heads, ray_div = S dividing 256): the workgroup composites the
+    // 256 / S rays whose samples it has just evaluated; raw_density / raw_rgb are then not written
+    const float* t_vals;       // [n_rays, S+1]
+    const float* dirs;         // [n_rays, 3]
+    float* comp_rgb;           // [n_rays, 3]
+    float* distance;           // [n_rays]
+    float* acc;                // [n_rays]
+    float* weights;            // [n_rays, S] nullable
+    int white_bkgd;
+    ActParams act;
 };
+constexpr int kFuseLds = 256 * 4 * 4;     // raw density + rgb of a workgroup's 256 samples
 
 // ------------------------------------------------------------------------------------------------
 // Weight stream: 1 KiB pieces consumed strictly in order.  Stage = the pieces of one output tile.
@@ -534,8 +546,9 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
 // grid = nblk / 4 workgroups of 512 threads; every buffer indexed by block is allocated for nblk (a
 // multiple of 4) blocks of 64 samples; samples >= M are padding (zero encodings in, nothing written
 // to the per-sample outputs).
-template <class N, bool SAVE>
+template <class N, bool SAVE, bool FUSE = false>
 __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
+    static_assert(!FUSE || (!SAVE && !N::SAR), "the fused render epilogue is for NeRF inference");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* cst = (float*)smem;
     const int tid = threadIdx.x;
@@ -635,6 +648,34 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
         d = rstd * (d - mean * sc[6]) + sc[7];
     }
     const float ang1 = __shfl_xor(hd_colour[0], 32);      // row 4 lives in lane half 1
+    if constexpr (FUSE) {
+        // utils.py:283-318 on the samples this workgroup holds: raw outputs go to LDS, one wave per ray composites
+        float* dl = (float*)(smem + N::FWD_LDS);
+        float* rl = dl + 256;
+        const int loc = (wave >> 1) * 64 + ct * 32 + c;
+        if (h == 0) {
+            dl[loc] = d;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) rl[loc * 3 + o] = sigmoid_f(hd_colour[o]);
+        }
+        __syncthreads();
+        const int S = a.ray_div, per = 256 / S;
+        for (int j = wave; j < per; j += kWaves) {
+            const int64_t ray = (int64_t)blockIdx.x * per + j;
+            if (ray >= a.n_rays) break;
+            const float* t = a.t_vals + ray * (S + 1);
+            const RaySums<0> r = composite_ray<0>(rl + j * S * 3, nullptr, dl + j * S, t, ray_dnorm(a.dirs + ray * 3), S, lane,
+                                                  a.act, a.weights ? a.weights + ray * S : nullptr, nullptr, nullptr, nullptr);
+            if (lane == 0) {
+                const float bg = a.white_bkgd ? (1.f - r.acc) : 0.f;
+#pragma unroll
+                for (int o = 0; o < 3; ++o) a.comp_rgb[ray * 3 + o] = r.c[o] + bg;
+                a.acc[ray] = r.acc;
+                a.distance[ray] = expected_distance(r.num, r.acc, t[0], t[S], nullptr);
+            }
+        }
+        return;
+    }
     if (m < a.M && h == 0) {
         a.raw_density[m] = d;
 #pragma unroll
@@ -1390,15 +1431,19 @@ static inline bool make_dims(const nerf_mlp_dims* d, HostDims* o) {
                              NERF_NET_LIST_5(X) NERF_NET_LIST_6(X)
 #define NERF_NET_LIST(X) NERF_NET_LIST_0(X) NERF_NET_LIST_BIG(X)
 
-template <class N, bool SAVE>
+template <class N, bool SAVE, bool FUSE = false>
 static int launch_fwd_t(const MlpFwdArgs& a, hipStream_t st) {
     static std::atomic<unsigned long long> done{0};
-    if (!allow_dynamic_lds((const void*)mlp_fwd_kernel<N, SAVE>, N::FWD_LDS, done)) return NERF_ERR_LAUNCH;
-    hipLaunchKernelGGL((mlp_fwd_kernel<N, SAVE>), dim3((unsigned)(a.nblk / 4)), dim3(64 * kWaves), N::FWD_LDS, st, a);
+    constexpr int lds = N::FWD_LDS + (FUSE ? kFuseLds : 0);
+    if (!allow_dynamic_lds((const void*)mlp_fwd_kernel<N, SAVE, FUSE>, lds, done)) return NERF_ERR_LAUNCH;
+    hipLaunchKernelGGL((mlp_fwd_kernel<N, SAVE, FUSE>), dim3((unsigned)(a.nblk / 4)), dim3(64 * kWaves), lds, st, a);
     return nerf_launch_status();
 }
 template <class N>
 int launch_fwd(const MlpFwdArgs& a, hipStream_t st) {
+    if constexpr (!N::SAR && !N::F8) {
+        if (a.comp_rgb != nullptr) return launch_fwd_t<N, false, true>(a, st);
+    }
     return a.tx[0] != nullptr ? launch_fwd_t<N, true>(a, st) : launch_fwd_t<N, false>(a, st);
 }
 
@@ -1580,11 +1625,49 @@ extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const f
     a.raw_rgb = raw_rgb;
     a.raw_angle = raw_angle;
     a.ln_stats = ln_stats;
+    a.t_vals = a.dirs = nullptr;
+    a.comp_rgb = a.distance = a.acc = a.weights = nullptr;
+    a.white_bkgd = 0;
+    a.act = make_act(nullptr);
 #define X(ht_, wt_, dks_, vks_, sar_)                                                             \
     if (d.HT == ht_ && d.WT == wt_ && d.DKS == dks_ && d.VKS == vks_ && (d.sar != 0) == sar_)     \
         return (acts && tfrag_fmt == NERF_TFRAG_E4M3)                                             \
                    ? launch_fwd<Net<ht_, wt_, dks_, vks_, sar_, true>>(a, nerf_stream(stream))    \
                    : launch_fwd<Net<ht_, wt_, dks_, vks_, sar_, false>>(a, nerf_stream(stream));
+    NERF_NET_LIST(X)
+#undef X
+    return NERF_ERR_SIZE;
+}
+
+// Forward chain + volume rendering of one level in one launch (inference): the workgroup that evaluates 256
+// consecutive samples composites the 256 / num_samples rays they belong to, so raw density and colour never go
+// to HBM.  num_samples must divide 256; NeRF heads only.
+extern "C" int nerf_mlp_fwd_composite(const nerf_mlp_dims* dims, const void* wfwd, const float* consts,
+                                      const void* enc_frag, const void* view_frag, int64_t n_rays, int num_samples,
+                                      const float* t_vals, const float* dirs, int white_bkgd,
+                                      const nerf_activation* act, float* comp_rgb, float* distance, float* acc,
+                                      float* weights, void* stream) {
+    if (n_rays == 0) return NERF_OK;
+    HostDims d;
+    NERF_REQUIRE(make_dims(dims, &d) && wfwd && consts && enc_frag && (view_frag || d.V == 0));
+    NERF_REQUIRE(t_vals && dirs && comp_rgb && distance && acc && n_rays > 0 && num_samples > 0);
+    if (d.sar || 256 % num_samples != 0) return NERF_ERR_SIZE;
+    MlpFwdArgs a = {};
+    a.wfwd = (const bf16x8*)wfwd;
+    a.consts = consts;
+    a.enc = (const bf16x8*)enc_frag;
+    a.view = (const bf16x8*)view_frag;
+    a.M = n_rays * num_samples;
+    a.nblk = ((a.M + 255) / 256) * 4;
+    a.ray_div = num_samples;
+    a.n_rays = (int)n_rays;
+    a.t_vals = t_vals; a.dirs = dirs;
+    a.comp_rgb = comp_rgb; a.distance = distance; a.acc = acc; a.weights = weights;
+    a.white_bkgd = white_bkgd;
+    a.act = make_act(act);
+#define X(ht_, wt_, dks_, vks_, sar_)                                                             \
+    if (d.HT == ht_ && d.WT == wt_ && d.DKS == dks_ && d.VKS == vks_ && (d.sar != 0) == sar_)     \
+        return launch_fwd<Net<ht_, wt_, dks_, vks_, sar_, false>>(a, nerf_stream(stream));
     NERF_NET_LIST(X)
 #undef X
     return NERF_ERR_SIZE;

@@ -20,6 +20,8 @@ _lib.register('nerf_view_frag', c_int, [_P, c_int64, c_int, c_int, _P, _P])
 _lib.register('nerf_mlp_fwd', c_int, [POINTER(MlpDims), _P, _P, _P, _P, c_int64, c_int, c_int64, POINTER(c_void_p),
                                       c_int, _P, _P, _P, _P, _P])
 
+_lib.register('nerf_mlp_fwd_composite', c_int, [POINTER(MlpDims), _P, _P, _P, _P, c_int64, c_int, _P, _P, c_int,
+                                                POINTER(_lib.NerfActivation), _P, _P, _P, _P, _P])
 _lib.register('nerf_mlp_bwd', c_int, [POINTER(MlpDims), _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, POINTER(c_void_p),
                                       POINTER(c_void_p), c_int, _P])
 class WgradDesc(ctypes.Structure):
@@ -457,6 +459,32 @@ def query_nerf(model, t_vals, rays, viewf, S):
         d, rgb, _, _, _ = mlp_forward(packed_for(model, need_bwd=False), encf, viewf, n * S, S, n, save=False)
         return d.reshape(-1, 1), rgb
     return _MlpNerf.apply(model, encf, viewf, n * S, S, n, *params)
+
+
+def can_render_level(model, S):
+    """The fused inference launch (forward chain + compositing) exists for the NeRF heads when the samples of whole
+    rays fill a 256-sample workgroup tile and nothing needs the raw outputs."""
+    return (256 % S == 0 and not torch.is_grad_enabled() and not getattr(model, 'return_raw', False)
+            and not (model.randomized and model.density_noise))
+
+
+def render_level(model, t_vals, rays, viewf, S, need_weights=True):
+    """One level of model.py:113-141 in one launch: fenceposts in, composited colour / distance / acc (and the
+    sample weights the next level resamples from) out.  Inference only (see can_render_level)."""
+    cfg = model.config
+    n = t_vals.shape[0]
+    dev = t_vals.device
+    encf = encode_frag(t_vals, rays.origins, rays.directions, rays.radii, model.ray_shape, cfg.min_deg, cfg.max_deg)
+    pk = packed_for(model, need_bwd=False)
+    comp, dist, acc = torch.empty(n, 3, device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev)
+    weights = torch.empty(n, S, device=dev) if need_weights else None
+    act = _lib.NerfActivation(1, float(model.rgb_padding), float(model.density_bias))
+    with profiling.timed('mlp_fwd_kernel', flops=pk.fwd_flops * n * S, bytes_=0.0):
+        check(lib().nerf_mlp_fwd_composite(ctypes.byref(pk.dims), _raw(pk.wfwd), ptr(pk.consts), _raw(encf),
+                                           _raw(viewf) if pk.view else None, n, S, ptr(f32c(t_vals)),
+                                           ptr(f32c(rays.directions).reshape(n, 3)), int(bool(model.white_bkgd)),
+                                           ctypes.byref(act), ptr(comp), ptr(dist), ptr(acc), ptr(weights), stream()))
+    return comp, dist, acc, weights
 
 
 SAR_PARAM_NAMES = [n + s for n in STREAMED + ['final_density.0', 'final_density.1', 'final_rgb.0', 'final_angle.0']

@@ -207,6 +207,15 @@ class MipNeRF(_RenderModule):
                         ur = (u_rand[l] if u_rand is not None else
                               torch.empty(n, S + 1, device=o.device).uniform_(0, 1 / (S + 1) - float(torch.finfo(torch.float32).eps)))
                     t_vals = ops.resample(t_vals, weights, S + 1, self.resample_padding, ur, blur=True)
+            if self._precision() == 'bf16':
+                from . import mlp_bf16
+                if mlp_bf16.can_render_level(self, S):      # inference: MLP and compositing of the level in one launch
+                    comp_rgb, distance, acc, weights = mlp_bf16.render_level(self, t_vals, rays, view_feat, S,
+                                                                             need_weights=l + 1 < len(levels))
+                    comp_rgbs.append(comp_rgb)
+                    distances.append(distance)
+                    accs.append(acc)
+                    continue
             raw_density, raw_rgb = self._query(t_vals, rays, view_feat, S)
             raw_density = raw_density.reshape(n, S, 1)
             raw_rgb = raw_rgb.reshape(n, S, 3)

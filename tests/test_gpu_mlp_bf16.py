@@ -498,3 +498,32 @@ def test_in_place_gradient_accumulation_matches_autograd():
         assert float((x - 0.25).abs().max()) > 0                       # a gradient did arrive
         # atomics add onto 0.25 term by term, autograd adds one finished sum: a few ulps of 0.25 apart
         assert float((x - y).abs().max()) <= 1e-5 * float((x - 0.25).abs().max()) + 3e-7
+
+
+@pytest.mark.parametrize('kw,levels,n', [(dict(), [64, 128], 301), (dict(hidden=64, num_samples=16, max_deg=4), [16, 16], 77),
+                                         (dict(use_viewdirs=False, white_bkgd=True), [64, 128], 130)])
+def test_fused_render_level_matches_separate_launches(monkeypatch, kw, levels, n):
+    """Inference renders a level in ONE launch (forward chain + compositing in its epilogue, nerf_mlp_fwd_composite):
+    colour, distance and acc of both levels equal those of the separate forward and compositing launches bit for
+    bit (the fine level's fenceposts come from the coarse level's weights, so those are covered too)."""
+    from nerf_amd import mlp_bf16
+    from nerf_amd.model import MipNeRF
+    from nerf_amd.utils import Rays
+    cfg = make_cfg(randomized=False, level_samples=levels, **kw)
+    torch.manual_seed(2)
+    m = MipNeRF(cfg).cuda().eval()
+    r = make_rays(n, 8)
+    rays = Rays(*(x.cuda() for x in (r.origins, r.directions, r.viewdirs, r.radii, r.lossmult, r.near, r.far)))
+    calls = []
+    real = mlp_bf16.render_level
+    monkeypatch.setattr(mlp_bf16, 'render_level', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        fused = m(rays)
+    assert len(calls) == 2
+    monkeypatch.setattr(mlp_bf16, 'can_render_level', lambda model, S: False)
+    with torch.no_grad():
+        sep = m(rays)
+    assert len(calls) == 2
+    for a, b in zip(fused, sep):
+        assert torch.equal(a, b)
+    assert bool(torch.isfinite(fused[0]).all()) and float(fused[2].max()) > 0
