@@ -71,13 +71,14 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const f32x16& v, int first) {
     return __builtin_bit_cast(bf16x8, d);
 }
 
-// Sign bits of the 8 bf16 of piece s (0/1) of a tile: dword q of the piece lands on bits 4s+q (low half)
-// and 16+4s+q (high half) -- a tile's 16 units fill bits 0..7 and 16..23 of a word.
-__device__ __forceinline__ unsigned piece_sign_bits(bf16x8 o, int s) {
+// Sign words: the sign bits of the 16 dwords (32 bf16 units per lane) of a pair of tiles; dword g = 8 (nt & 1) + 4 s + q
+// (tile of the pair, piece s, dword q) puts the sign of its low half on bit g and of its high half on bit 16 + g.
+// Built by shifting: each dword's two sign bits enter at bits 15 and 31 and move down one place per dword pushed
+// after them (a shift and one and-or per dword); a word that received a single tile is 8 places short.
+__device__ __forceinline__ unsigned push_sign_bits(unsigned w, bf16x8 o) {
     const u32x4 d = __builtin_bit_cast(u32x4, o);
-    unsigned w = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) w |= ((d[q] >> 15) & 0x00010001u) << (4 * s + q);
+    for (int q = 0; q < 4; ++q) w = (w >> 1) | (d[q] & 0x80008000u);
     return w;
 }
 // Zero the units whose keep-bit is clear (keep = inverted sign word of the saved pre-activation).
@@ -493,7 +494,7 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 o = pack_bf16x8(acc, 8 * s);
-            if (kMask) signs |= piece_sign_bits(o, s) << (8 * (nt & 1));
+            if (kMask) signs = push_sign_bits(signs, o);
             if (RELU) o = relu_bf16(o);
             out[2 * nt + s] = o;
         }
@@ -507,6 +508,7 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
                 __builtin_nontemporal_store(out[2 * nt + s], &fsave[(((b32 >> 1) * (2 * NT) + 2 * nt + s) * 2 + (b32 & 1)) * 64 + lane]);
         }
         if (kMask && ((nt & 1) || nt + 1 == NT)) {
+            if constexpr (!(nt & 1)) signs >>= 8;       // an odd tile count: the last word holds one tile
             __builtin_nontemporal_store(signs, &msave[(b32 * ((NT + 1) / 2) + (nt >> 1)) * 64 + lane]);
             signs = 0;
         }

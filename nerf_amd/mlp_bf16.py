@@ -46,6 +46,9 @@ TFRAG_FORMATS = {'bf16': 0, 'e4m3': 1}
 DEFAULT_WGRAD_OPERANDS = 'e4m3'
 
 
+_FOLD_SPLIT_K = 8       # K slices of the small fp32 products around the folded colour layer (few output tiles)
+
+
 def _raw(t):
     """Device pointer of any contiguous tensor (byte buffers, bf16 fragments)."""
     assert t.is_cuda and t.is_contiguous()
@@ -93,6 +96,8 @@ class Packed:
             self.W8, self.b8 = f32c(p['rgb_net0.0.weight']), f32c(p['rgb_net0.0.bias'])
             self.W9 = f32c(p['rgb_net1.0.weight'])
             fold = self.W9.clone()
+            # (no split-K here: its atomic sums would make the bf16 rounding of the folded matrix vary from one
+            # packing of the same weights to the next)
             fold[:, :H] = gemm(self.W9, (H + V, 1), self.W8, (H, 1), W, H, H)                        # W9[:, :H] @ W8
             bias9 = gemm(self.b8, (H, 1), self.W9, (1, H + V), 1, W, H, bias=f32c(p['rgb_net1.0.bias']))[0]  # b8 W9a^T + b9
             tail = [fold, f32c(self.head_density), f32c(self.head_colour)]
@@ -329,10 +334,11 @@ def fold_gradients(pk, grads):
     H, W, V = pk.H, pk.W, pk.V
     G, s = grads['_g98.weight'], grads['_g98.bias']
     g9, g8 = grads['rgb_net1.0.weight'], grads['rgb_net0.0.weight']
-    gemm(G, (H, 1), pk.W8, (1, H), W, H, H, split_k=2, out=g9)                        # += G W8^T   (columns 0..H-1)
+    k = _FOLD_SPLIT_K
+    gemm(G, (H, 1), pk.W8, (1, H), W, H, H, split_k=k, out=g9)                        # += G W8^T   (columns 0..H-1)
     gemm(s, (1, 1), pk.b8, (H, 1), W, H, 1, split_k=2, out=g9)                        # += s b8^T
-    gemm(pk.W9, (1, H + V), G, (H, 1), H, H, W, split_k=2, out=g8)                    # += W9a^T G
-    gemm(pk.W9, (1, H + V), s, (1, 1), H, 1, W, split_k=2, out=grads['rgb_net0.0.bias'].view(H, 1))   # += W9a^T s
+    gemm(pk.W9, (1, H + V), G, (H, 1), H, H, W, split_k=k, out=g8)                    # += W9a^T G
+    gemm(pk.W9, (1, H + V), s, (1, 1), H, 1, W, split_k=k, out=grads['rgb_net0.0.bias'].view(H, 1))   # += W9a^T s
     grads['rgb_net1.0.bias'].add_(s)
 
 
