@@ -157,7 +157,12 @@ __device__ __forceinline__ unsigned emit_tfrag8_scaled(void* dst, int64_t b32, i
     float amax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(t[r]));
-    amax = fmaxf(amax, __shfl_xor(amax, 32));                       // the other 16 samples of the block
+    {   // the other 16 samples of the block sit 32 lanes away: swap two copies between the lane halves (a register
+        // exchange, no trip through LDS); every lane then holds its own value in one copy, its partner's in the other
+        const unsigned x = __float_as_uint(amax);
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        amax = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
     const int field = (int)(__float_as_uint(amax) >> 23);            // biased exponent of the largest magnitude
     const unsigned e = (unsigned)(field > 8 ? field - 7 : 1);        // largest magnitude / 2^(e - 127) in [128, 256)
     const float scale = __uint_as_float(e << 23);                    // 2^(e - 127); the conversion divides by it
