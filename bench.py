@@ -120,9 +120,9 @@ def launch_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
-def cpu_baseline(budget_rays=192, threads=None):
-    """The CPU oracle (fp32 restatement of the reference path) on a bounded sample of the same workload:
-    fwd + loss + bwd at 64+128 samples per ray, all host cores torch gives us."""
+def cpu_baseline(budget_rays=2048, threads=None):
+    """The CPU oracle (fp32 restatement of the reference path) on a bounded sample of the same workload: the full
+    step (fwd + loss + bwd + AdamW) at 64+128 samples per ray, all host cores torch gives us."""
     from oracle import nerf_oracle as O
     if threads:
         torch.set_num_threads(threads)
@@ -136,6 +136,7 @@ def cpu_baseline(budget_rays=192, threads=None):
                   torch.full((n, 1), 6.))
     tgt = torch.rand(n, 3, generator=g)
     eps = float(torch.finfo(torch.float32).eps)
+    opt = torch.optim.AdamW(list(p.values()), lr=cfg.lr_init, weight_decay=cfg.weight_decay)
 
     def step():
         t_rand = torch.rand(n, 65, generator=g)
@@ -143,8 +144,8 @@ def cpu_baseline(budget_rays=192, threads=None):
         out = O.nerf_render(p, rays, cfg, [64, 128], t_rand, u_rand)
         loss, _ = O.nerf_loss(out['comp_rgb_stack'], tgt, rays.lossmult, cfg.coarse_weight_decay)
         loss.backward()
-        for v in p.values():
-            v.grad = None
+        opt.step()
+        opt.zero_grad(set_to_none=True)
     step()
     t0 = time.perf_counter()
     reps = 0
@@ -155,7 +156,7 @@ def cpu_baseline(budget_rays=192, threads=None):
             break
     dt = (time.perf_counter() - t0) / reps
     return dict(value=n / dt, unit='rays/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'{n} rays x (64+128) samples, fwd+loss+bwd (no optimizer), {reps} reps, fp32 torch-CPU oracle')
+                sample=f'{n} rays x (64+128) samples per step, fwd+loss+bwd+AdamW, {reps} steps timed, fp32 torch-CPU oracle')
 
 
 def main():
