@@ -275,7 +275,7 @@ int nerf_view_frag(const float* dirs, int64_t n_rays, int min_deg, int max_deg, 
  * backward pass reads: [0..7], [9] the outputs X0..X7 of the trunk layers and X9 of the colour layer as transposed
  * bf16 fragments (nblk * features * 128 bytes each, nblk = 4 * ceil(M / 256); [8] unused, may be NULL: rgb_net0's
  * output is never formed), [10..19] their ReLU sign words (nblk * 2 *
- * ceil(features / 64) * 256 bytes; [18] unused, may be NULL), [20] / [21] the position encoding and
+ * ceil(features / 256) * 1024 bytes; [18] unused, may be NULL), [20] / [21] the position encoding and
  * view features as transposed fragments, [22] (SAR only) the trunk output in fragment order (nblk * H_padded
  * * 128 bytes).  With tfrag_fmt = NERF_TFRAG_E4M3 the transposed-fragment buffers [0..9], [20], [21] hold e4m3 and
  * need half the bytes.  Without view directions view_frag, [9], [19] and [21] are unused (may be NULL).

@@ -75,6 +75,20 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const f32x16& v, int first) {
 // (tile of the pair, piece s, dword q) puts the sign of its low half on bit g and of its high half on bit 16 + g.
 // Built by shifting: each dword's two sign bits enter at bits 15 and 31 and move down one place per dword pushed
 // after them (a shift and one and-or per dword); a word that received a single tile is 8 places short.
+// A layer's sign words are kept per lane in chunks of four (one 16-byte store or load per lane and chunk, a full
+// 1 KiB per wave): buffer [block of 32][chunks][64 lanes][4 words], chunks = ceil(words / 4), words = ceil(tiles / 2).
+__device__ __host__ constexpr int sign_chunks(int tiles) { return ((tiles + 1) / 2 + 3) / 4; }
+template <int NW, int KW>
+__device__ __forceinline__ void load_sign_words(unsigned (&w)[KW], const unsigned* buf, int64_t b32, int lane) {
+    constexpr int NC = (NW + 3) / 4;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const u32x4 v = ((const u32x4*)buf)[(b32 * NC + c) * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * c + k < NW) w[4 * c + k] = v[k];
+    }
+}
 __device__ __forceinline__ unsigned push_sign_bits(unsigned w, bf16x8 o) {
     const u32x4 d = __builtin_bit_cast(u32x4, o);
 #pragma unroll
@@ -294,9 +308,9 @@ constexpr StageDesc fwd_stage(int i) {
                         N::HKS + N::VKS, N::WKS};
     // 0 head (nothing saved), 2 saved + sign words, 3 as 2 + a frag-order copy (SAR trunk output)
     const int kind[kL] = {2, 2, 2, 2, 2, 2, 2, N::SAR ? 3 : 2, 0, 2, 0};
-    // stores that finishing tile t of layer l issues: 2 T-frag pieces, + the sign word after every second tile
+    // stores that finishing tile t of layer l issues: the T-frag pieces, + a chunk of four sign words after every eighth tile
     auto tile_stores = [&](int l, int t) {
-        return (!SAVE || kind[l] == 0) ? 0 : N::TPIECES + ((kind[l] >= 2 && ((t & 1) || t + 1 == tiles[l])) ? 1 : 0) + (kind[l] == 3 ? 2 : 0);
+        return (!SAVE || kind[l] == 0) ? 0 : N::TPIECES + ((kind[l] >= 2 && ((t & 7) == 7 || t + 1 == tiles[l])) ? 1 : 0) + (kind[l] == 3 ? 2 : 0);
     };
     if (i < 0) return {0, 0, 0, 0};
     for (int l = 0; l < kL; ++l) {
@@ -326,7 +340,7 @@ constexpr StageDesc bwd_stage(int i) {
             int st = 0;
             for (int t = t0; t < t1; ++t) st += t > 0 ? N::TPIECES : 0;
             // (the previous layer's last tile: 2 bf16 pieces, or 1 e4m3 piece + the scale bytes)
-            return {ks[l] * (t1 - t0), (i == 0 && l > (N::VIEW ? 0 : 1)) ? 2 : 0, (i == 0 && masked[l + 1]) ? (tiles[l + 1] + 1) / 2 : 0, st};
+            return {ks[l] * (t1 - t0), (i == 0 && l > (N::VIEW ? 0 : 1)) ? 2 : 0, (i == 0 && masked[l + 1]) ? sign_chunks(tiles[l + 1]) : 0, st};
         }
         i -= stage_count(tiles[l]);
     }
@@ -469,6 +483,7 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
     constexpr bool kMask = SAVE && RELU;
     const int lane = pipe.lane;
     unsigned signs = 0;
+    u32x4 sign_chunk = {0u, 0u, 0u, 0u};
 #define NERF_FS(i) fwd_stage<N, SAVE>(i)
     constexpr int NS = stage_count(NT);
     static_assert(NERF_FS(STAGE0).ks == KS * (NT < kTPS ? NT : kTPS) && NERF_FS(STAGE0 + NS).ks != NERF_FS(STAGE0 + NS - 1).ks + 12345,
@@ -514,8 +529,10 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
         }
         if (kMask && ((nt & 1) || nt + 1 == NT)) {
             if constexpr (!(nt & 1)) signs >>= 8;       // an odd tile count: the last word holds one tile
-            __builtin_nontemporal_store(signs, &msave[(b32 * ((NT + 1) / 2) + (nt >> 1)) * 64 + lane]);
+            sign_chunk[(nt >> 1) & 3] = signs;
             signs = 0;
+            if constexpr ((nt & 7) == 7 || nt + 1 == NT)
+                __builtin_nontemporal_store(sign_chunk, (u32x4*)msave + (b32 * sign_chunks(NT) + (nt >> 3)) * 64 + lane);
         }
     };
     f32x16 prev;
@@ -737,7 +754,7 @@ __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[K
     unsigned sc_lo = 0, sc_hi = 0;          // e4m3 form: the scale bytes of this layer's tiles
 #define NERF_BS(i) bwd_stage<N>(i)
     constexpr int NS = stage_count(NT);
-    static_assert(NERF_BS(STAGE0).ks == KS * (NT < kTPS ? NT : kTPS) && NERF_BS(STAGE0).xloads == NW_NEXT,
+    static_assert(NERF_BS(STAGE0).ks == KS * (NT < kTPS ? NT : kTPS) && NERF_BS(STAGE0).xloads == (NW_NEXT + 3) / 4,
                   "stage table out of step");
     auto finish = [&](auto ntc, const f32x16& raw) __attribute__((always_inline)) {
         constexpr int nt = decltype(ntc)::value;
@@ -768,10 +785,7 @@ __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[K
         constexpr int T0 = st * kTPS, TN = (NT - T0) < kTPS ? (NT - T0) : kTPS;
         constexpr int KSN = NERF_BS(STAGE0 + st + kRing - 1).ks, NLD = stage_loads(KSN);
         pipe.template begin_prefetch<KSN>();      // its loads go out one at a time under the first tile's MFMAs
-        if (st == 0) {
-#pragma unroll
-            for (int i = 0; i < NW_NEXT; ++i) nextw[i] = next_mask[(b32 * NW_NEXT + i) * 64 + lane];
-        }
+        if constexpr (st == 0 && NW_NEXT > 0) load_sign_words<NW_NEXT>(nextw, next_mask, b32, lane);
         static_for<0, TN>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value, nt = T0 + j;
             f32x16 acc;
@@ -874,11 +888,9 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
     }
     unsigned kw9[WW > 0 ? WW : 1], kwa[HW], kwb[HW], nokw[1] = {0u};
     if constexpr (N::VIEW) {
-#pragma unroll
-        for (int i = 0; i < WW; ++i) kw9[i] = a.mask[9][(b32 * WW + i) * 64 + lane];
+        load_sign_words<WW>(kw9, a.mask[9], b32, lane);
     } else {
-#pragma unroll
-        for (int i = 0; i < HW; ++i) kwa[i] = a.mask[7][(b32 * HW + i) * 64 + lane];
+        load_sign_words<HW>(kwa, a.mask[7], b32, lane);
     }
     if constexpr (N::F8) {
         if constexpr (N::VIEW) store_scales(a.tsc[10], b32, lane, emit_tfrag8_scaled(a.tdy_hd, b32, 1, 0, lane, dz, zero, P), 0u);

@@ -235,7 +235,8 @@ def act_block_bytes(pk):
     piece = 4096 >> pk.fmt                          # transposed fragments: bf16 or e4m3
     used = lambda i, t: i != 8 and t > 0            # (no X8 since the fold; no X9 without view directions)
     per = [t * piece if used(i, t) else None for i, t in enumerate(tiles)]
-    per += [2 * ((t + 1) // 2) * 256 if used(i, t) else None for i, t in enumerate(tiles)]
+    # ReLU sign words: per block of 32 samples, chunks of four words per lane (ceil(ceil(tiles / 2) / 4) KiB)
+    per += [2 * (((t + 1) // 2 + 3) // 4) * 1024 if used(i, t) else None for i, t in enumerate(tiles)]
     per += [pk.DT * piece, pk.VT * piece if pk.view else None]
     if pk.sar:
         per.append(32 * pk.HT * 128)
