@@ -255,13 +255,18 @@ def dy_block_bytes(pk):
 
 def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False, acts=None, raw=None):
     """-> raw_density [M], raw_rgb [M,3], raw_angle [M,2] or None, acts (list of byte buffers) or None.
-    `acts` (buffers laid out as act_block_bytes says) and `raw = (raw_density, raw_rgb)` may be supplied by a
-    caller that owns persistent buffers; otherwise they are allocated here."""
+    `acts` (buffers laid out as act_block_bytes says) and `raw = (raw_density, raw_rgb)` (SAR: `(raw_density,
+    raw_rgb, raw_angle, ln_stats)`) may be supplied by a caller that owns persistent buffers; otherwise they are
+    allocated here."""
     dev = enc.device
     nblk = n_blocks(n_samples)
-    raw_density, raw_rgb = raw if raw is not None else (torch.empty(n_samples, device=dev), torch.empty(n_samples, 3, device=dev))
-    raw_angle = torch.empty(n_samples, 2, device=dev) if pk.sar else None
-    ln_stats = torch.empty(n_samples, 2, device=dev) if (pk.sar and save) else None
+    raw_angle = ln_stats = None
+    if raw is not None and len(raw) == 4:           # SAR caller with persistent buffers
+        raw_density, raw_rgb, raw_angle, ln_stats = raw
+    else:
+        raw_density, raw_rgb = raw if raw is not None else (torch.empty(n_samples, device=dev), torch.empty(n_samples, 3, device=dev))
+        raw_angle = torch.empty(n_samples, 2, device=dev) if pk.sar else None
+        ln_stats = torch.empty(n_samples, 2, device=dev) if (pk.sar and save) else None
     arr = None
     if acts is not None:
         arr = (c_void_p * len(acts))(*[a.data_ptr() if a is not None else None for a in acts])
@@ -526,19 +531,22 @@ class _MlpSar(torch.autograd.Function):
         grads['_heads.bias'] = torch.zeros(5, device=dev)
         mlp_weight_grads(pk, ctx.acts, dys, ctx.n, grads)
         ctx.acts = None
-        # d = sum_f w_f (gamma_f xhat_f + beta_f) + b, xhat = (x - mean) rstd:
-        # A_f = sum_m g rstd x_f, B = sum_m g rstd mean, Sg = sum_m g  ->  dL/d(w gamma)_f = A_f - B
-        gamma, beta = P['final_density.0.weight'], P['final_density.0.bias']
-        w = P['final_density.1.weight'][0]
-        du = grads['_dens.weight'][0] - grads['_dens.bias'][1]
-        sg = grads['_dens.bias'][2]
-        grads['final_density.1.weight'] = (gamma * du + beta * sg)[None]
-        grads['final_density.1.bias'] = sg[None]
-        grads['final_density.0.weight'] = w * du
-        grads['final_density.0.bias'] = w * sg
-        grads['final_rgb.0.weight'], grads['final_rgb.0.bias'] = grads['_heads.weight'][:3], grads['_heads.bias'][:3]
-        grads['final_angle.0.weight'], grads['final_angle.0.bias'] = grads['_heads.weight'][3:], grads['_heads.bias'][3:]
+        grads.update(sar_head_gradients(P, grads))
         return (None, None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
+
+
+def sar_head_gradients(P, grads):
+    """Gradients of the SAR heads from the sums the weight-gradient pass left in the scratch pairs `_dens`, `_heads`.
+    d = sum_f w_f (gamma_f xhat_f + beta_f) + b, xhat = (x - mean) rstd:
+    A_f = sum_m g rstd x_f, B = sum_m g rstd mean, Sg = sum_m g  ->  dL/d(w gamma)_f = A_f - B."""
+    gamma, beta = P['final_density.0.weight'], P['final_density.0.bias']
+    w = P['final_density.1.weight'][0]
+    du = grads['_dens.weight'][0] - grads['_dens.bias'][1]
+    sg = grads['_dens.bias'][2]
+    return {'final_density.1.weight': (gamma * du + beta * sg)[None], 'final_density.1.bias': sg[None],
+            'final_density.0.weight': w * du, 'final_density.0.bias': w * sg,
+            'final_rgb.0.weight': grads['_heads.weight'][:3], 'final_rgb.0.bias': grads['_heads.bias'][:3],
+            'final_angle.0.weight': grads['_heads.weight'][3:], 'final_angle.0.bias': grads['_heads.bias'][3:]}
 
 
 def query_sar(model, t_vals, origins, ray_d, radii, viewf, R, S):

@@ -135,6 +135,147 @@ class NerfStepper:
         return cwd * sq[:-1].sum() + sq[-1], self.comp
 
 
+def sar_supported(model):
+    """The fused SAR step covers the bf16 network without density noise (model.py:362-363)."""
+    cfg = model.config
+    return (getattr(cfg, 'mlp_precision', 'fp32') == 'bf16' and not (model.randomized and model.density_noise)
+            and not getattr(model, 'return_raw', False) and hasattr(model, 'rays_per_chunk'))
+
+
+class SarStepper:
+    """One SAR pulse (model.py:305-387 + loss + backward) as a fixed launch sequence on persistent buffers.
+
+    The forward runs the ray chunks and sampling levels one after another, each pass (chunk, level) into its own
+    slice of every saved buffer (whole 256-sample tiles).  The matched filter and the loss (model.py:377-380,
+    util_modules.py:74-89) go through torch's autograd with the accumulated range profiles as leaves; their gradient
+    is scattered back per pass (`nerf_scatter_bwd`), and then ONE backward chain and ONE weight-gradient launch per
+    layer cover the samples of all passes, adding into the parameters' `.grad`."""
+
+    def __init__(self, model):
+        self.model = model
+        self.dev = dev = model.device
+        pk = mlp_bf16.packed_for(model, need_bwd=True)
+        self.R, self.S, self.L = model.rays_per_chunk, model.num_samples, model.num_levels
+        self.passes = model.num_ray_iters * self.L
+        nb = mlp_bf16.n_blocks(self.R * self.S)
+        self.nblk, self.nblk_total = nb, nb * self.passes
+        u8 = lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.act_bytes = mlp_bf16.act_block_bytes(pk)
+        self.dy_bytes = mlp_bf16.dy_block_bytes(pk)
+        self.acts = [u8(self.nblk_total * b) if b is not None else None for b in self.act_bytes]
+        self.dys = [u8(self.nblk_total * b) if b is not None else None for b in self.dy_bytes]
+        m_all = 64 * self.nblk_total
+        z = lambda *shape: torch.zeros(*shape, device=dev)      # (padding samples of a pass stay zero: no gradient)
+        self.raw_density, self.raw_rgb, self.raw_angle, self.ln_stats = z(m_all), z(m_all, 3), z(m_all, 2), z(m_all, 2)
+        self.g_density, self.g_rgb, self.g_angle = z(m_all), z(m_all, 3), z(m_all, 2)
+        self.dens_w, self.dens_b = z(3, pk.H), z(3)
+        self.heads_w, self.heads_b = z(5, pk.W if pk.view else pk.H), z(5)
+
+    def _slice(self, bufs, per_block, q):
+        lo, hi = q * self.nblk, (q + 1) * self.nblk
+        return [b[lo * pb:hi * pb] if b is not None else None for b, pb in zip(bufs, per_block)]
+
+    def step(self, ray_o, mfilt, _radii, _near, _far, nsam, mpp, target, az_el=None, t_rand=None, u_rand=None):
+        """-> loss (device scalar).  Arguments as SARNeRF.forward; the weight gradients are ADDED into `.grad`."""
+        from . import ops
+        from .model import SAR_AZ_SIGMA, SAR_EL_SIGMA
+        model, dev, R, S, L = self.model, self.dev, self.R, self.S, self.L
+        cfg = model.config
+        pk = mlp_bf16.packed_for(model, need_bwd=True)
+        L_ = lib()
+        st = stream()
+        f32 = lambda x: torch.as_tensor(x, dtype=torch.float32, device=dev).reshape(-1)
+        near_s, far_s, rad_s, mpp_s = f32(_near)[0], f32(_far)[0], f32(_radii)[0], f32(mpp)[0]
+        near, far, radii = near_s.expand(R).contiguous(), far_s.expand(R).contiguous(), rad_s.expand(R).contiguous()
+        pulse_bins = (torch.arange(nsam, device=dev) * mpp_s + near_s).contiguous()                # model.py:316
+        origins = ray_o.to(dev, torch.float32).reshape(1, 3).expand(R, 3).contiguous()
+        act = ctypes.byref(NerfActivation(1, float(model.rgb_padding), float(model.density_bias)))
+        wl = float(model.wavelength)
+        M = R * S
+        comp = [torch.zeros(nsam, 2, device=dev) for _ in range(L)]
+        saved, statuses = [], []
+        i32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.int32)
+        for c in range(model.num_ray_iters):
+            if az_el is not None:
+                az, el = az_el[c]
+            else:                                                                              # model.py:319-320
+                az, el = torch.randn(R) * SAR_AZ_SIGMA, torch.randn(R) * SAR_EL_SIGMA
+            ray_d, ray_p = ops.sar_raygen(az.to(dev), el.to(dev))
+            viewf = mlp_bf16.view_frag(ray_d, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg) if pk.view else None
+            t_vals = weights = None
+            for l in range(L):
+                q = c * L + l
+                if l == 0:
+                    tr = None
+                    if model.randomized:
+                        tr = t_rand[c] if t_rand is not None else torch.rand(R, S + 1, device=dev)
+                    t_vals = ops.stratified_t(near, far, S, tr, False)
+                else:
+                    ur = None
+                    if model.randomized:
+                        ur = (u_rand[c] if u_rand is not None else
+                              torch.empty(R, S + 1, device=dev).uniform_(0, 1 / (S + 1) - _EPS32))
+                    t_vals = ops.resample(t_vals, weights, S + 1, model.resample_padding, ur, blur=True)
+                encf = mlp_bf16.encode_frag(t_vals, origins, ray_d, radii, model.ray_shape, cfg.min_deg, cfg.max_deg)
+                lo = 64 * q * self.nblk
+                raw = tuple(t[lo:lo + M] for t in (self.raw_density, self.raw_rgb, self.raw_angle, self.ln_stats))
+                mlp_bf16.mlp_forward(pk, encf, viewf, M, R, R, save=True, acts=self._slice(self.acts, self.act_bytes, q), raw=raw)
+                pulse, dist, acc = torch.empty(nsam, 2, device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev)
+                weights, alpha = torch.empty(R, S, device=dev), torch.empty(R, S, device=dev)
+                ray_ret, ray_bin, comp5 = torch.empty(R, 2, device=dev), i32(R), torch.empty(R, 5, device=dev)
+                winner, status = i32(nsam), i32(1)
+                check(L_.nerf_scatter_fwd(ptr(raw[1]), ptr(raw[2]), ptr(raw[0]), ptr(ray_p), ptr(t_vals), ptr(ray_d),
+                                          ptr(pulse_bins), R, S, nsam, wl, act, ptr(pulse), ptr(dist), ptr(acc),
+                                          ptr(weights), ptr(alpha), ptr(ray_ret), ptr(ray_bin, torch.int32), ptr(comp5),
+                                          ptr(winner, torch.int32), ptr(status, torch.int32), st))
+                comp[l] += pulse
+                saved.append((ray_p, t_vals, ray_d, ray_bin, comp5, dist))
+                statuses.append(status)
+        if getattr(cfg, 'check_range', True) and int(torch.cat(statuses).min()) != 0:
+            raise IndexError('range bin index out of bounds: a ray distance lies beyond the last pulse bin '
+                             '(far > near + (nsam - 1) * mpp)')
+        # matched filter, per-pulse normalisation and loss through autograd, with the range profiles as leaves
+        leaves = [x.requires_grad_(True) for x in comp]
+        mf = mfilt.to(dev)
+        outs = []
+        for l in range(L):                                                                     # model.py:377-380
+            zc = torch.view_as_complex(leaves[l][None].contiguous())
+            zc = torch.fft.ifft(mf * torch.fft.fft(zc, mf.shape[-1], dim=-1), dim=-1)[..., :nsam]
+            outs.append(torch.view_as_real(zc / torch.std(zc, dim=-1)[..., None]))
+        loss, _ = model.loss_function.level_losses(torch.stack(outs), target.to(dev))
+        g_comp = torch.autograd.grad(loss, leaves)
+        for q, (ray_p, t_vals, ray_d, ray_bin, comp5, dist) in enumerate(saved):
+            lo = 64 * q * self.nblk
+            sl = lambda t: t[lo:lo + M]
+            check(L_.nerf_scatter_bwd(ptr(sl(self.raw_rgb)), ptr(sl(self.raw_angle)), ptr(sl(self.raw_density)), ptr(ray_p),
+                                      ptr(t_vals), ptr(ray_d), ptr(g_comp[q % L].contiguous()), ptr(ray_bin, torch.int32),
+                                      ptr(comp5), ptr(dist), None, None, R, S, nsam, wl, act, ptr(sl(self.g_rgb)),
+                                      ptr(sl(self.g_angle)), ptr(sl(self.g_density)), st))
+        m_all = 64 * self.nblk_total
+        mlp_bf16.mlp_backward(pk, self.acts, m_all, self.g_density, self.g_rgb, self.raw_rgb, self.g_angle, self.raw_density,
+                              self.raw_angle, self.ln_stats, dys=self.dys, n_real=M * self.passes)
+        P = {k: v.detach() for k, v in model.named_parameters()}
+        grads = {k: q.grad for k, q in model.named_parameters() if q.requires_grad}
+        for t in (self.dens_w, self.dens_b, self.heads_w, self.heads_b):
+            t.zero_()
+        grads.update({'_dens.weight': self.dens_w, '_dens.bias': self.dens_b, '_heads.weight': self.heads_w,
+                      '_heads.bias': self.heads_b})
+        mlp_bf16.mlp_weight_grads(pk, self.acts, self.dys, m_all, grads)
+        for k, g in mlp_bf16.sar_head_gradients(P, grads).items():
+            grads[k].add_(g)
+        return loss.detach()
+
+
+def sar_stepper_for(model):
+    s = getattr(model, '_sar_stepper', None)
+    if (s is None or s.dev != model.device or (s.R, s.S, s.L) != (model.rays_per_chunk, model.num_samples, model.num_levels)
+            or s.passes != model.num_ray_iters * model.num_levels):
+        model._sar_stepper = None
+        s = SarStepper(model)
+        model._sar_stepper = s
+    return s
+
+
 def stepper_for(model, n_rays):
     s = getattr(model, '_stepper', None)
     if s is None or s.n != n_rays or s.levels != model._level_samples() or s.dev != model.device:

@@ -179,7 +179,7 @@ def allreduce_sum_shared_loss(x, world_size):
     return x if world_size <= 1 else _AllReduceSumSharedLoss.apply(x)
 
 
-def sar_train_step(model, batch, optimizer, rank=0, world_size=1, scheduler=None, **draws):
+def sar_train_step(model, batch, optimizer, rank=0, world_size=1, scheduler=None, fused=True, **draws):
     """One SAR pulse, ray chunks dealt round-robin to the ranks (model.py:326-375 loops over them on one device).
 
     The reference ADDS the chunks' range profiles before the matched filter (model.py:371), and within a chunk
@@ -190,6 +190,17 @@ def sar_train_step(model, batch, optimizer, rank=0, world_size=1, scheduler=None
     ray_o, pan, tilt, mfilt, radii, near, far, mpp, pulse_data = batch
     bucket = grad_bucket(model)
     bucket.zero()
+    from . import stepper
+    if fused and world_size == 1 and stepper.sar_supported(model):
+        # the pulse as a fixed launch sequence: one backward chain and one weight-gradient pass for all passes
+        loss = stepper.sar_stepper_for(model).step(ray_o, mfilt, radii, near, far, pulse_data.shape[1], mpp, pulse_data,
+                                                   **draws)
+        bucket.attach()
+        optimizer.step()
+        if scheduler is not None:
+            scheduler.step()
+        model._weights_changed()
+        return loss
     pulses = model(ray_o, pan, tilt, mfilt, radii, near, far, pulse_data.shape[1], mpp, rank=rank,
                    world_size=world_size, **draws)[0]
     loss, _ = model.loss_function.level_losses(pulses, pulse_data.to(pulses.device))      # (the PSNRs go to the host)

@@ -218,3 +218,38 @@ def test_sar_chunks_dealt_to_two_ranks_match_one_device():
         # chunk order changes only the order of fp32 sums (profiles, split-K atomics)
         assert np.linalg.norm(grads - one_grads) <= 2e-3 * np.linalg.norm(one_grads)
     assert np.array_equal(got[0][2], got[1][2])
+
+
+@pytest.mark.parametrize('tag', ['rand', 'det_noview'])
+def test_fused_sar_step_matches_the_autograd_step(golden, tag):
+    """The SAR pulse as a fixed launch sequence (`nerf_amd.stepper.SarStepper`: one backward chain and one
+    weight-gradient pass over all chunks and levels) against the autograd path on the same kernels and draws: the
+    same loss and the same gradients up to the order of fp32 atomic sums."""
+    from tests.conftest import T, cfg_from
+    from nerf_amd.model import SARNeRF
+    from nerf_amd.train import sar_train_step
+    fx = golden('sar_e2e_' + tag)
+    cfg = cfg_from(fx)
+    cfg.wavelength = 40.0
+    cfg.mlp_precision = 'bf16'
+    m = SARNeRF(cfg).cuda().train()
+    m.load_state_dict(O.init_params(cfg, sar=True, seed=int(fx['wseed'])), strict=False)
+    chunks = cfg.total_num_rays // cfg.rays_per_chunk
+    draws = dict(az_el=[(T(fx[f'az_{c}']), T(fx[f'el_{c}'])) for c in range(chunks)])
+    if cfg.randomized:
+        draws.update(t_rand=[T(fx[f't_rand_{c}']).cuda() for c in range(chunks)],
+                     u_rand=[T(fx[f'u_rand_{c}']).cuda() for c in range(chunks)])
+    mfilt = torch.complex(T(fx['mfilt_re']), T(fx['mfilt_im']))
+    batch = (T(fx['ray_o']), None, None, mfilt, T(fx['radii']), T(fx['near']), T(fx['far']), T(fx['mpp']), T(fx['target']))
+    out = []
+    for fused in (False, True):
+        opt = torch.optim.SGD(m.parameters(), lr=0.0)
+        loss = sar_train_step(m, batch, opt, fused=fused, **draws)
+        out.append((float(loss), {k: p.grad.clone() for k, p in m.named_parameters() if p.requires_grad}))
+    assert getattr(m, '_sar_stepper', None) is not None
+    assert abs(out[0][0] - out[1][0]) < 1e-5 * abs(out[0][0]), (out[0][0], out[1][0])
+    scale = max(float(g.norm()) for g in out[0][1].values())
+    for k, a in out[0][1].items():
+        b = out[1][1][k]
+        assert torch.isfinite(b).all(), k
+        assert float((a - b).norm()) <= 2e-4 * float(a.norm()) + 1e-6 * scale, (k, float((a - b).norm()), float(a.norm()))
