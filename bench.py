@@ -84,13 +84,20 @@ def sar_batch(dev, nsam=2048, nfft=8192, seed=0):
 def sar_pulse_step(model, batch, opt, world):
     """One SAR training step on this rank's own pulse; with several ranks the gradient bucket is averaged (a batch
     of `world` pulses, where the reference's loader delivers one, params.yaml:99)."""
-    from nerf_amd.train import grad_bucket
+    from nerf_amd import stepper
+    from nerf_amd.train import grad_bucket, sar_train_step
+    if world == 1:
+        return sar_train_step(model, batch, opt)
     ray_o, pan, tilt, mfilt, radii, near, far, mpp, target = batch
     bucket = grad_bucket(model)
     bucket.zero()
-    pulses = model(ray_o, pan, tilt, mfilt, radii, near, far, target.shape[1], mpp)[0]
-    loss, _ = model.loss_function(pulses, target)
-    (loss / world).backward()
+    if stepper.sar_supported(model):
+        loss = stepper.sar_stepper_for(model).step(ray_o, mfilt, radii, near, far, target.shape[1], mpp, target)
+        bucket.flat.mul_(1.0 / world)
+    else:
+        pulses = model(ray_o, pan, tilt, mfilt, radii, near, far, target.shape[1], mpp)[0]
+        loss, _ = model.loss_function(pulses, target)
+        (loss / world).backward()
     bucket.attach()
     bucket.all_reduce(world)
     opt.step()

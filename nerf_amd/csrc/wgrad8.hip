@@ -262,9 +262,11 @@ static bool wgrad8_config(int NT, int KT, int* WN, int* WK, int* tn, int* tk) {
     return *tn != 0;
 }
 
-// Instantiations with a compile-time load count: the launches of the 8 x 256 network (colour width 128).
+// Instantiations with a compile-time load count: the launches of the 8 x 256 network (colour width 128) and of the
+// SAR network (hidden 156, colour width 180).
 static int wgrad8_static_loads(int tn, int tk, int loads) {
-    static const int kStatic[5][3] = {{4, 4, 8}, {2, 2, 5}, {4, 5, 9}, {5, 3, 7}, {1, 1, 3}};
+    static const int kStatic[10][3] = {{4, 4, 8}, {2, 2, 5}, {4, 5, 9}, {5, 3, 7}, {1, 1, 3},
+                                       {3, 3, 5}, {3, 3, 6}, {4, 4, 7}, {2, 2, 3}, {1, 2, 4}};
     for (const auto& v : kStatic)
         if (v[0] == tn && v[1] == tk && v[2] == loads) return loads;
     return 0;
@@ -310,6 +312,7 @@ int nerf_wgrad8_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint
     const int gs = wgrad8_static_loads(tn, tk, loads);
 #define NERF_W8S(n_, k_, g_) if (tn == n_ && tk == k_ && gs == g_) return launch_wgrad8<n_, k_, g_>(a, grid, lds, st);
     NERF_W8S(4, 4, 8) NERF_W8S(2, 2, 5) NERF_W8S(4, 5, 9) NERF_W8S(5, 3, 7) NERF_W8S(1, 1, 3)
+    NERF_W8S(3, 3, 5) NERF_W8S(3, 3, 6) NERF_W8S(4, 4, 7) NERF_W8S(2, 2, 3) NERF_W8S(1, 2, 4)
 #undef NERF_W8S
 #define NERF_W8(n_, k_) if (tn == n_ && tk == k_) return launch_wgrad8<n_, k_, 0>(a, grid, lds, st);
     NERF_W8(1, 1) NERF_W8(1, 2) NERF_W8(2, 2) NERF_W8(2, 3) NERF_W8(3, 3) NERF_W8(4, 4) NERF_W8(4, 5) NERF_W8(5, 3) NERF_W8(5, 4)
