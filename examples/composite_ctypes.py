@@ -1,5 +1,5 @@
 """Binding one entry point of libnerf_amd.so by hand: alpha compositing (the reference's utils.py:283-318 with the
-activation glue of model.py:139-140 fused in front).  INTEGRATION.md quotes the block between the markers."""
+activation glue of model.py:139-140 fused in front).  The integration guide quotes the block between the markers."""
 # --- begin snippet
 import ctypes, os, torch
 

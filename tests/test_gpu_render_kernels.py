@@ -435,7 +435,7 @@ def test_c_abi_rejects_bad_arguments():
 
 
 def test_integration_snippet_runs(ops):
-    """The hand-written ctypes binding quoted in INTEGRATION.md (examples/composite_ctypes.py) calls
+    """The hand-written ctypes binding quoted in the integration guide (examples/composite_ctypes.py) calls
     nerf_composite_fwd with the prototype's 14 arguments and returns what `ops.composite` returns; the document
     quotes the file verbatim."""
     import importlib.util
