@@ -338,6 +338,10 @@ typedef struct nerf_wgrad_desc {
     float* gb[2];
     int tfrag_fmt;             /* NERF_TFRAG_BF16 or NERF_TFRAG_E4M3: the format of dy[] and x[] */
     const void* dy_scale[2];   /* NERF_TFRAG_E4M3: the scale bytes of dy[] (what nerf_mlp_bwd wrote beside them) */
+    void* workspace;           /* optional (NERF_TFRAG_E4M3): device scratch for a two-stage flush of the workgroups'
+                                * partial sums instead of float atomics from all of them; 96 MiB covers every shape;
+                                * NULL or too small: atomics.  Its contents mean nothing between calls. */
+    int64_t workspace_bytes;
 } nerf_wgrad_desc;
 int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint, void* stream);
 

@@ -31,6 +31,7 @@ struct Wgrad8Args {
     int64_t nblk;                  // blocks of 64 samples = k-steps
     int NT, KT, WN, WK;
     int depth;
+    float* partial;                // two-stage flush: [workgroup][wave][tile of the wave (+ 2 bias tiles)][16][64] or NULL
 };
 constexpr int kWg8MaxLoads = 10;   // data loads per wave and k-step: 2 (NT + KT) pieces over 4 waves (+ 1 for scale bytes)
 
@@ -199,6 +200,29 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS write may outlive the workgroup
 
+    // Two-stage flush: with 256 workgroups adding the same 64 K addresses at once the float atomics of a 256 x 256
+    // output take 75-100 us per launch; plain stores of the partial tiles (coalesced, 1 KiB per wave instruction) and
+    // one reduction over the workgroups (wgrad8_reduce_kernel) take a third of that.
+    if (a.partial != nullptr) {
+        f32x4* pw = (f32x4*)(a.partial + ((int64_t)blockIdx.x * 4 + wave) * (NTW * KTW + 2) * 1024);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int j = 0; j < KTW; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const f32x4 x = {acc[i][j][4 * v], acc[i][j][4 * v + 1], acc[i][j][4 * v + 2], acc[i][j][4 * v + 3]};
+                    __builtin_nontemporal_store(x, &pw[((i * KTW + j) * 4 + v) * 64 + lane]);
+                }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const f32x4 x = {accb[s][4 * v], accb[s][4 * v + 1], accb[s][4 * v + 2], accb[s][4 * v + 3]};
+                __builtin_nontemporal_store(x, &pw[((NTW * KTW + s) * 4 + v) * 64 + lane]);
+            }
+        return;
+    }
     // flush: accumulator element r of lane l is dW[row tile*32 + acc_row(r, l>>5)][col tile*32 + (l&31)]
     const int h = lane >> 5, c = lane & 31;
 #pragma unroll
@@ -236,12 +260,60 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
     }
 }
 
+// Second stage of the two-stage flush: sums the partial tiles of `nwg` workgroups and adds them into the gradients.
+// One thread per (wave, tile, register quad, lane) and slice of workgroups (blockIdx.y of gridDim.y slices).
+__global__ void wgrad8_reduce_kernel(Wgrad8Args a, int nwg, int NTW, int KTW) {
+    const int tiles = NTW * KTW + 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 4 * tiles * 256) return;
+    const int lane = idx & 63, v = (idx >> 6) & 3, tile = (idx >> 8) % tiles, wave = (idx >> 8) / tiles;
+    const int per = (nwg + gridDim.y - 1) / gridDim.y;
+    const int w0 = blockIdx.y * per, w1 = w0 + per < nwg ? w0 + per : nwg;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    const int64_t stride = (int64_t)4 * tiles * 256;           // f32x4 per workgroup
+    const f32x4* p = (const f32x4*)a.partial + ((int64_t)w0 * 4 + wave) * tiles * 256 + (tile * 4 + v) * 64 + lane;
+    for (int w = w0; w < w1; ++w, p += stride) sum += __builtin_nontemporal_load(p);
+    const int wn = wave / a.WK, wk = wave % a.WK;
+    const int h = lane >> 5, c = lane & 31;
+    if (tile < NTW * KTW) {
+        const int i = tile / KTW, j = tile % KTW;
+        const int nt = wn * NTW + i, kt = wk * KTW + j;
+        if (nt >= a.NT || kt >= a.KT) return;
+        const int sa = nt >= a.A[0].tiles, lt = sa ? nt - a.A[0].tiles : nt;
+        const int sb = kt >= a.B[0].tiles, lk = sb ? kt - a.B[0].tiles : kt;
+        const WgradOut o = a.out[sa][sb];
+        const int k = lk * 32 + c;
+        if (o.G == nullptr || k >= a.B[sb].n_true) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nn = lt * 32 + acc_row(4 * v + q, h);
+            if (nn < a.A[sa].n_true) atomicAdd(&o.G[(int64_t)nn * o.ld + o.col0 + k], sum[q]);
+        }
+    } else {            // bias sums: tiles wk and wk + WK of the wave's row; column 0 holds them
+        const int s = tile - NTW * KTW;
+        const int ii = wk + s * a.WK, nt = wn * NTW + ii;
+        if (c != 0 || ii >= NTW || nt >= a.NT) return;
+        const int sa = nt >= a.A[0].tiles, lt = sa ? nt - a.A[0].tiles : nt;
+        if (a.gb[sa] == nullptr) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nn = lt * 32 + acc_row(4 * v + q, h);
+            if (nn < a.A[sa].n_true) atomicAdd(&a.gb[sa][nn], sum[q]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int NTW, int KTW, int GS>
 static int launch_wgrad8(const Wgrad8Args& a, unsigned grid, size_t lds, hipStream_t st) {
     static std::atomic<unsigned long long> done{0};
     if (!allow_dynamic_lds((const void*)mlp_wgrad8_kernel<NTW, KTW, GS>, kWgradLds, done)) return NERF_ERR_LAUNCH;
     hipLaunchKernelGGL((mlp_wgrad8_kernel<NTW, KTW, GS>), dim3(grid), dim3(256), lds, st, a);
+    if (a.partial != nullptr) {
+        const int threads = 4 * (NTW * KTW + 2) * 256;
+        hipLaunchKernelGGL(wgrad8_reduce_kernel, dim3((threads + 255) / 256, grid >= 64 ? 8 : 1), dim3(256), 0, st, a,
+                           (int)grid, NTW, KTW);
+    }
     return nerf_launch_status();
 }
 
@@ -310,6 +382,10 @@ int nerf_wgrad8_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint
     if ((int64_t)grid > a.nblk) grid = (unsigned)a.nblk;
     const size_t lds = (size_t)(a.depth * (pieces + 1) + 4) * 1024;
     const int gs = wgrad8_static_loads(tn, tk, loads);
+    // two-stage flush when the caller lends a workspace that holds every workgroup's partial tiles and the output
+    // is large enough for the atomics to matter
+    const int64_t need = (int64_t)grid * 4 * (tn * tk + 2) * 1024 * 4;
+    a.partial = (d->workspace != nullptr && d->workspace_bytes >= need && tn * tk >= 4) ? (float*)d->workspace : nullptr;
 #define NERF_W8S(n_, k_, g_) if (tn == n_ && tk == k_ && gs == g_) return launch_wgrad8<n_, k_, g_>(a, grid, lds, st);
     NERF_W8S(4, 4, 8) NERF_W8S(2, 2, 5) NERF_W8S(4, 5, 9) NERF_W8S(5, 3, 7) NERF_W8S(1, 1, 3)
     NERF_W8S(3, 3, 5) NERF_W8S(3, 3, 6) NERF_W8S(4, 4, 7) NERF_W8S(2, 2, 3) NERF_W8S(1, 2, 4)

@@ -29,7 +29,7 @@ class WgradDesc(ctypes.Structure):
     _fields_ = [('dy', c_void_p * 2), ('dy_feat', c_int * 2), ('dy_true', c_int * 2),
                 ('x', c_void_p * 2), ('x_feat', c_int * 2), ('x_true', c_int * 2),
                 ('G', (c_void_p * 2) * 2), ('ld', (c_int * 2) * 2), ('col0', (c_int * 2) * 2), ('gb', c_void_p * 2),
-                ('tfrag_fmt', c_int), ('dy_scale', c_void_p * 2)]
+                ('tfrag_fmt', c_int), ('dy_scale', c_void_p * 2), ('workspace', c_void_p), ('workspace_bytes', c_int64)]
 
 
 _lib.register('nerf_mlp_wgrad_multi', c_int, [POINTER(WgradDesc), c_int64, c_int, _P])
@@ -372,10 +372,26 @@ def mlp_weight_grads(pk, acts, dys, n_samples, grads):
     fold_gradients(pk, grads)
 
 
+_WGRAD_WORKSPACE = {}
+WGRAD_WORKSPACE_BYTES = 96 << 20
+
+
+def _wgrad_workspace(dev):
+    """Scratch for the two-stage flush of the 8-bit weight-gradient launches (one buffer per device, reused by
+    every launch: launches on a stream run one after another)."""
+    ws = _WGRAD_WORKSPACE.get(dev)
+    if ws is None:
+        ws = _WGRAD_WORKSPACE[dev] = torch.empty(WGRAD_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
+    return ws
+
+
 def _wgrad_launches(pk, acts, dys, n_samples, grads):
+    ws = _wgrad_workspace(pk.consts.device) if pk.fmt else None
     for dsegs, xsegs, blocks in _wgrad_plan(pk):
         d = WgradDesc()
         d.tfrag_fmt = pk.fmt
+        if ws is not None:
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
         flops = 0.0
         for i, (di, nf, nt, name) in enumerate(dsegs):
             d.dy[i], d.dy_feat[i], d.dy_true[i] = dys[di].data_ptr(), nf, nt
