@@ -527,3 +527,37 @@ def test_fused_render_level_matches_separate_launches(monkeypatch, kw, levels, n
     for a, b in zip(fused, sep):
         assert torch.equal(a, b)
     assert bool(torch.isfinite(fused[0]).all()) and float(fused[2].max()) > 0
+
+
+def test_empty_ragged_batches_and_ray_independence():
+    """Batches of 0, 1, 63 and 257 rays (no whole tile, one partly filled tile, a tile boundary inside a ray) on the
+    bf16 path, inference and training step; and rays are rendered independently of their batch: the first 63 rays
+    of the 257-ray batch come out bit for bit as the 63-ray batch does."""
+    from nerf_amd.model import MipNeRF
+    from nerf_amd.train import nerf_train_step
+    from nerf_amd.utils import Rays, namedtuple_map
+    cfg = make_cfg(randomized=False, level_samples=[64, 128])
+    torch.manual_seed(5)
+    m = MipNeRF(cfg).cuda()
+    r = make_rays(257, 21)
+    full = Rays(*(x.cuda() for x in (r.origins, r.directions, r.viewdirs, r.radii, r.lossmult, r.near, r.far)))
+    pix = torch.rand(257, 3, device='cuda')
+    outs = {}
+    for n in (0, 1, 63, 257):
+        rays = namedtuple_map(lambda t: t[:n], full)
+        m.eval()
+        with torch.no_grad():
+            rgb, dist, acc = m(rays)
+        assert rgb.shape == (2, n, 3) and dist.shape[-1] == n and acc.shape[-1] == n
+        assert bool(torch.isfinite(rgb).all())
+        outs[n] = (rgb, dist, acc)
+        if n == 0:
+            continue
+        m.train()
+        opt = torch.optim.SGD(m.parameters(), lr=0.0)
+        loss = nerf_train_step(m, rays, pix[:n], opt, chunk=max(n, 1))
+        assert bool(torch.isfinite(loss)) and all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.requires_grad)
+    for a, b in zip(outs[63], outs[257]):
+        assert torch.equal(a, b[..., :63, :] if a.dim() == 3 else b[..., :63])
+    for a, b in zip(outs[1], outs[63]):
+        assert torch.equal(a, b[..., :1, :] if a.dim() == 3 else b[..., :1])
