@@ -491,13 +491,7 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
     // finish tile nt from its accumulator: activation, bf16 B operand of the next layer, saved copies
     auto finish = [&](auto ntc, const f32x16& raw) __attribute__((always_inline)) {
         constexpr int nt = decltype(ntc)::value;
-        f32x16 acc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {       // accumulator rows 8g + 4h .. + 3 of the tile
-            const f32x4 b = *(const f32x4*)(bias + nt * 32 + 8 * g + 4 * h);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[4 * g + q] = raw[4 * g + q] + b[q];
-        }
+        const f32x16& acc = raw;            // (the bias is already in it: the accumulator started from it)
         if (EPI == EPI_HEAD) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) head[q] = acc[q];          // rows 4h .. 4h+3 of the tile
@@ -543,9 +537,15 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
         pipe.template begin_prefetch<KSN>();      // its loads go out one at a time under the first tile's MFMAs
         static_for<0, TN>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value, nt = T0 + j;
+            // the accumulator starts from the bias (four LDS reads straight into its registers) instead of from
+            // zero plus sixteen additions in the epilogue
             f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int g = 0; g < 4; ++g) {       // accumulator rows 8g + 4h .. + 3 of the tile
+                const f32x4 b = *(const f32x4*)(bias + nt * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = b[q];
+            }
             pipe.template tile<KS, j * KS>(acc, [&](auto kc) __attribute__((always_inline)) {
                 constexpr int ks = decltype(kc)::value;
                 if constexpr (ks < KS_M) return xm[ks];
