@@ -71,10 +71,8 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const f32x16& v, int first) {
     return __builtin_bit_cast(bf16x8, d);
 }
 
-// Sign words: the sign bits of the 16 dwords (32 bf16 units per lane) of a pair of tiles; dword g = 8 (nt & 1) + 4 s + q
-// (tile of the pair, piece s, dword q) puts the sign of its low half on bit g and of its high half on bit 16 + g.
-// Built by shifting: each dword's two sign bits enter at bits 15 and 31 and move down one place per dword pushed
-// after them (a shift and one and-or per dword); a word that received a single tile is 8 places short.
+// Sign words: the sign bits of the 16 dwords (32 bf16 units per lane) of a pair of tiles in one 32-bit word per lane;
+// bit positions: tile_sign_bits / sign_pos below (the second tile of a pair sits four places lower).
 // A layer's sign words are kept per lane in chunks of four (one 16-byte store or load per lane and chunk, a full
 // 1 KiB per wave): buffer [block of 32][chunks][64 lanes][4 words], chunks = ceil(words / 4), words = ceil(tiles / 2).
 __device__ __host__ constexpr int sign_chunks(int tiles) { return ((tiles + 1) / 2 + 3) / 4; }
@@ -89,17 +87,28 @@ __device__ __forceinline__ void load_sign_words(unsigned (&w)[KW], const unsigne
             if (4 * c + k < NW) w[4 * c + k] = v[k];
     }
 }
-__device__ __forceinline__ unsigned push_sign_bits(unsigned w, bf16x8 o) {
-    const u32x4 d = __builtin_bit_cast(u32x4, o);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w = (w >> 1) | (d[q] & 0x80008000u);
+// The 16 sign bits of a tile (pieces o0, o1) by byte gathers: v_perm_b32 collects the high bytes of two dwords
+// (low halves in bytes 0-1, high halves in bytes 2-3), whose top bits are the signs; the four gathered words are
+// shifted against one another and merged.  Dword g = 2 i + e of the tile (g = 4 s + q) leaves the sign of its low half
+// on bit 8 e + 7 - i and of its high half 16 above: sign_pos(g).  12 instructions per tile against 16.
+__device__ __host__ constexpr int sign_pos(int g) { return 8 * (g & 1) + 7 - (g >> 1); }
+__device__ __forceinline__ unsigned tile_sign_bits(bf16x8 o0, bf16x8 o1) {
+    const u32x4 a = __builtin_bit_cast(u32x4, o0), b = __builtin_bit_cast(u32x4, o1);
+    // perm(hi, lo, sel): bytes 0..3 index lo, 4..7 index hi; result bytes (low to high) = lo.b1, hi.b1, lo.b3, hi.b3
+    const unsigned sel = 0x07030501u;
+    const unsigned t0 = __builtin_amdgcn_perm(a[1], a[0], sel), t1 = __builtin_amdgcn_perm(a[3], a[2], sel);
+    const unsigned t2 = __builtin_amdgcn_perm(b[1], b[0], sel), t3 = __builtin_amdgcn_perm(b[3], b[2], sel);
+    unsigned w = t0 & 0x80808080u;
+    w |= (t1 >> 1) & 0x40404040u;
+    w |= (t2 >> 2) & 0x20202020u;
+    w |= (t3 >> 3) & 0x10101010u;
     return w;
 }
 // Zero the units whose keep-bit is clear (keep = inverted sign word of the saved pre-activation).
 __device__ __forceinline__ bf16x8 piece_apply_keep(bf16x8 g, unsigned keep, int s) {
     u32x4 m;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) m[q] = (keep >> (4 * s + q)) & 0x00010001u;
+    for (int q = 0; q < 4; ++q) m[q] = (keep >> sign_pos(4 * s + q)) & 0x00010001u;
     const u16x8 r = __builtin_bit_cast(u16x8, g) * __builtin_bit_cast(u16x8, m);
     return __builtin_bit_cast(bf16x8, r);
 }
@@ -142,9 +151,10 @@ __device__ __forceinline__ void emit_tfrag(bf16x8* dst, int64_t b32, int NT, int
 //          v_mfma_scale_f32_32x32x64_f8f6f4 along its reduction axis.  Activations are stored unscaled (e = 127).
 __device__ __forceinline__ u32x4 pack_fp8x16(const f32x16& t) {
     u32x4 o;
+    int w = 0;      // both halves of every word are overwritten: the previous word serves as the "old" operand (no move)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        int w = __builtin_amdgcn_cvt_pk_fp8_f32(t[4 * q], t[4 * q + 1], 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(t[4 * q], t[4 * q + 1], w, false);
         w = __builtin_amdgcn_cvt_pk_fp8_f32(t[4 * q + 2], t[4 * q + 3], w, true);
         o[q] = (unsigned)w;
     }
@@ -182,9 +192,9 @@ __device__ __forceinline__ unsigned emit_tfrag8_scaled(void* dst, int64_t b32, i
     const float scale = __uint_as_float(e << 23);                    // 2^(e - 127); the conversion divides by it
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     u32x4 o;
+    s16x2 w = {0, 0};       // (carried from word to word: both halves are overwritten each time)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        s16x2 w = {0, 0};
         w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, t[4 * q], t[4 * q + 1], scale, false);
         w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, t[4 * q + 2], t[4 * q + 3], scale, true);
         o[q] = __builtin_bit_cast(unsigned, w);
@@ -505,13 +515,15 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
                 ln[1] += x * x;
             }
         }
+        bf16x8 pre[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 o = pack_bf16x8(acc, 8 * s);
-            if (kMask) signs = push_sign_bits(signs, o);
+            if (kMask) pre[s] = o;
             if (RELU) o = relu_bf16(o);
             out[2 * nt + s] = o;
         }
+        if (kMask) signs |= tile_sign_bits(pre[0], pre[1]) >> (4 * (nt & 1));
         if (SAVE) {
             if constexpr (N::F8) emit_tfrag8(tsave, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
             else emit_tfrag(tsave, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
@@ -522,7 +534,6 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
                 __builtin_nontemporal_store(out[2 * nt + s], &fsave[(((b32 >> 1) * (2 * NT) + 2 * nt + s) * 2 + (b32 & 1)) * 64 + lane]);
         }
         if (kMask && ((nt & 1) || nt + 1 == NT)) {
-            if constexpr (!(nt & 1)) signs >>= 8;       // an odd tile count: the last word holds one tile
             sign_chunk[(nt >> 1) & 3] = signs;
             signs = 0;
             if constexpr ((nt & 7) == 7 || nt + 1 == NT)
@@ -768,7 +779,7 @@ __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[K
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 o = pack_bf16x8(acc, 8 * s);
-            if (MASKED) o = piece_apply_keep(o, ~keepw[MASKED ? nt >> 1 : 0] >> (8 * (nt & 1)), s);
+            if (MASKED) o = piece_apply_keep(o, ~keepw[MASKED ? nt >> 1 : 0] << (4 * (nt & 1)), s);
             out[2 * nt + s] = o;
         }
         if constexpr (N::F8) {
