@@ -350,8 +350,9 @@ int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_h
  * by kernel symbol.  (No reference counterpart: measurement support.) */
 int nerf_mlp_wgrad_config(int n_feat, int k_feat, int* nw, int* tn, int* tk, int* gt);
 /* The same for NERF_TFRAG_E4M3 launches: mlp_wgrad8_kernel<tn, tk, gs> (gs = compile-time data loads per wave and
- * k-step, 0 = run-time count). */
-int nerf_mlp_wgrad8_config(int n_feat, int k_feat, int* tn, int* tk, int* gs);
+ * k-step, 0 = run-time count); the count depends on how the features split into the two dY and two X segments of
+ * the launch (0 = segment absent). */
+int nerf_mlp_wgrad8_config(int n_feat0, int n_feat1, int k_feat0, int k_feat1, int* tn, int* tk, int* gs);
 
 #ifdef __cplusplus
 }

@@ -139,23 +139,32 @@ __device__ __forceinline__ void emit_tfrag(bf16x8* dst, int64_t b32, int NT, int
     }
 }
 
-// ---- 8-bit transposed fragments ("T-frag8") ----------------------------------------------------------------
-// The weight-gradient operands may be kept as OCP e4m3 instead of bf16 (half the bytes written by the chain kernels
-// and read by the weight-gradient pass; the chain itself stays bf16).  Layout of a buffer of F = 32 T features:
-//   data   [block of 32 samples][T tiles][64 lanes][16 bytes]: lane 32*hh + n holds feature n of the tile, byte r is
-//          sample (r & 3) + 8 (r >> 2) + 4 hh of the block -- the 16 accumulator registers of the transposing MFMAs as
-//          they stand, one 1 KiB piece per (block, tile);
+// ---- 8- and 6-bit transposed fragments ("T-frag8", "T-frag6") ------------------------------------------------
+// The weight-gradient operands may be kept in the OCP microscaling element formats instead of bf16 (the chain itself
+// stays bf16): activations as e4m3, 1 byte per element; gradients as e2m3 ("fp6"), 6 bits per element, with one
+// power-of-two scale per (feature, block of 32 samples).
+//   within-lane order: a lane of the transposing product holds 16 samples of its feature, accumulator register r
+//          being sample acc_row(r, hh) of the block.  Both formats keep them in the order tfrag8_reg(j), j = 0..15:
+//          registers 0, 8, 1, 9, ..., 7, 15 -- the order in which v_cvt_scalef32_2xpk16_fp6_f32 leaves its two
+//          sources (it interleaves them); the byte packing of the activations simply follows it.
+//   activations [block of 32 samples][T tiles][64 lanes][16 bytes]: lane 32*hh + n holds feature n of the tile, byte j
+//          is sample acc_row(tfrag8_reg(j), hh) of the block, unscaled e4m3; one 1 KiB piece per (block, tile);
+//   gradients   [block of 32 samples][T tiles][32 features n][2 lane halves hh][12 bytes]: element j (bits 6 j .. 6 j + 5)
+//          of the 96 bits of (n, hh) is sample acc_row(tfrag8_reg(j), hh), so the 24 bytes of feature n are the 32
+//          samples of the block as one e2m3 matrix-core operand; 768 bytes per (block, tile);
 //   scales [block of 32 samples][32 features n][8 bytes] (gradient buffers only): byte t is the E8M0 exponent e of
 //          (block, tile t, feature n): stored value = true value * 2^(127 - e), e >= 1 chosen so that the block's
-//          largest magnitude lands in [128, 256).  One exponent per (feature, 32 samples) is the MX block of
-//          v_mfma_scale_f32_32x32x64_f8f6f4 along its reduction axis.  Activations are stored unscaled (e = 127).
+//          largest magnitude lands in [4, 8) (e2m3 reaches 7.5; above that it saturates, the MX convention).  One
+//          exponent per (feature, 32 samples) is the MX block of v_mfma_scale_f32_32x32x64_f8f6f4 along its
+//          reduction axis.  Activations are unscaled (e = 127).
+__device__ __host__ constexpr int tfrag8_reg(int j) { return (j >> 1) + 8 * (j & 1); }
 __device__ __forceinline__ u32x4 pack_fp8x16(const f32x16& t) {
     u32x4 o;
     int w = 0;      // both halves of every word are overwritten: the previous word serves as the "old" operand (no move)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(t[4 * q], t[4 * q + 1], w, false);
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(t[4 * q + 2], t[4 * q + 3], w, true);
+    for (int q = 0; q < 4; ++q) {       // bytes 4 q .. 4 q + 3 = registers 2 q, 8 + 2 q, 2 q + 1, 9 + 2 q
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(t[2 * q], t[8 + 2 * q], w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(t[2 * q + 1], t[9 + 2 * q], w, true);
         o[q] = (unsigned)w;
     }
     return o;
@@ -174,10 +183,10 @@ __device__ __forceinline__ void emit_tfrag8(void* dst, int64_t b32, int NT, int 
     const f32x16 t = transpose_tile(p0, p1, P);
     __builtin_nontemporal_store(pack_fp8x16(t), (u32x4*)dst + (b32 * NT + nt) * 64 + lane);
 }
-// gradients: block-scaled e4m3; returns the E8M0 exponent of this lane's feature
+// gradients: block-scaled e2m3; returns the E8M0 exponent of this lane's feature
 __device__ __forceinline__ unsigned emit_tfrag8_scaled(void* dst, int64_t b32, int NT, int nt, int lane, bf16x8 p0,
                                                         bf16x8 p1, const bf16x8 (&P)[2]) {
-    f32x16 t = transpose_tile(p0, p1, P);
+    const f32x16 t = transpose_tile(p0, p1, P);
     float amax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(t[r]));
@@ -188,18 +197,17 @@ __device__ __forceinline__ unsigned emit_tfrag8_scaled(void* dst, int64_t b32, i
         amax = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
     }
     const int field = (int)(__float_as_uint(amax) >> 23);            // biased exponent of the largest magnitude
-    const unsigned e = (unsigned)(field > 8 ? field - 7 : 1);        // largest magnitude / 2^(e - 127) in [128, 256)
+    const unsigned e = (unsigned)(field > 3 ? field - 2 : 1);        // largest magnitude / 2^(e - 127) in [4, 8)
     const float scale = __uint_as_float(e << 23);                    // 2^(e - 127); the conversion divides by it
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
-    u32x4 o;
-    s16x2 w = {0, 0};       // (carried from word to word: both halves are overwritten each time)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, t[4 * q], t[4 * q + 1], scale, false);
-        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, t[4 * q + 2], t[4 * q + 3], scale, true);
-        o[q] = __builtin_bit_cast(unsigned, w);
-    }
-    __builtin_nontemporal_store(o, (u32x4*)dst + (b32 * NT + nt) * 64 + lane);
+    // The conversion interleaves its two 16-register sources; with registers 8..15 copied to the front of a second
+    // source the low 96 bits of the result are the lane's 16 values in the order tfrag8_reg (the rest is not used).
+    const f32x16 u = __builtin_shufflevector(t, t, 8, 9, 10, 11, 12, 13, 14, 15, -1, -1, -1, -1, -1, -1, -1, -1);
+    typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+    typedef unsigned u32x3 __attribute__((ext_vector_type(3), aligned(4)));     // (12 bytes stored, 12-byte stride)
+    const u32x6 w = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(t, u, scale);
+    const u32x3 o = {w[0], w[1], w[2]};
+    char* out = (char*)dst + (b32 * NT + nt) * 768 + (2 * (lane & 31) + (lane >> 5)) * 12;
+    __builtin_nontemporal_store(o, (u32x3*)out);
     return e;
 }
 // the exponents of up to 8 tiles of one block, by the lower lane half (both halves hold the same values)

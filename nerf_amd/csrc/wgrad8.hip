@@ -1,17 +1,21 @@
-// Weight gradients of the fused MLP from 8-bit operands (NERF_TFRAG_E4M3) for gfx950.
+// Weight gradients of the fused MLP from microscaling-format operands (NERF_TFRAG_E4M3) for gfx950.
 //
-// G[n][k] += sum_m dY[m][n] X[m][k] and gb[n] += sum_m dY[m][n], operands given as e4m3 transposed fragments
-// ("T-frag8": feature on the lane, samples in the bytes of the registers; layout in mlp_bf16.hip), gradients with
-// one power-of-two scale per (feature, block of 32 samples).  A pure streaming GEMM on
-// v_mfma_scale_f32_32x32x64_f8f6f4, HBM-bound: every operand byte is read once and feeds 2 x 256 FLOP.
+// G[n][k] += sum_m dY[m][n] X[m][k] and gb[n] += sum_m dY[m][n], operands given as transposed fragments (feature on
+// the lane, samples along the registers; layouts in mlp_bf16.hip): activations X as e4m3 ("T-frag8"), gradients dY as
+// e2m3 ("T-frag6") with one power-of-two scale per (feature, block of 32 samples).  A pure streaming GEMM on
+// v_mfma_scale_f32_32x32x64_f8f6f4 (A = dY in the fp6 format, B = X in the fp8 format), HBM-bound: every operand
+// byte is read once.
 //
-// Operand lane map of the instruction (checked with exact data, tools/microbench/mx_layout.hip): lane 32 kh + n holds
-// row n of the tile; its bytes 0..15 together with bytes 0..15 of the lane's other half are scale block 0, scaled by
-// the exponent that lane n supplies; bytes 16..31 of both halves are scale block 1, exponent supplied by lane 32 + n.
-// A k-step is one block of 64 samples = two producer blocks of 32: lane 32 kh + n takes bytes 0..15 from the piece
-// of sample block 2Q (exactly the 16 bytes the producing lane 32 kh + n wrote) and bytes 16..31 from the piece of
-// block 2Q + 1, and supplies the exponent of block 2Q + kh.  One hardware scale block = one producer block; no byte
-// is moved between lanes anywhere.  Activations carry exponent 127 (unscaled).
+// Operand lane maps of the instruction (checked with exact data, tools/microbench/mx_layout.hip, fp6_layout.hip).
+// A k-step is one block of 64 samples = two producer blocks of 32, 2Q and 2Q + 1.
+//   e4m3 (B): lane 32 kh + n holds column n; its bytes 0..15 are K = 16 kh + 0..15, bytes 16..31 K = 32 + 16 kh + 0..15.
+//          The lane takes bytes 0..15 from the piece of block 2Q (exactly the 16 bytes the producing lane 32 kh + n
+//          wrote) and bytes 16..31 from the piece of block 2Q + 1; activations carry exponent 127 (unscaled).
+//   e2m3 (A): lane 32 kh + n holds row n; its 32 elements (the low 192 bits of the operand) are K = 32 kh + 0..31 and
+//          take the exponent the same lane supplies.  The lane reads the 24 contiguous bytes of (block 2Q + kh,
+//          feature n): the 12 bytes of the producing lane half 0, then those of half 1 -- the same samples, in the same
+//          order, as the 32 bytes of K-block kh on the B side.
+// One hardware scale block = one producer block; no byte is moved between lanes anywhere.
 //
 // Four waves (one per SIMD) own the whole [NT x KT]-tile output in accumulator registers; workgroup b takes the
 // k-steps b, b + grid, ...; the pieces and scale bytes of a k-step go HBM -> LDS by global_load_lds into a ring
@@ -24,7 +28,7 @@
 typedef int v8i __attribute__((ext_vector_type(8)));
 
 struct Wgrad8Args {
-    WgradSeg A[2], B[2];           // dY side / X side segments (p = e4m3 data)
+    WgradSeg A[2], B[2];           // dY side (p = e2m3 data, 768 B per block and tile) / X side (e4m3, 1 KiB) segments
     const unsigned char* Asc[2];   // scale bytes of the dY segments: [block of 32 samples][32 n][8]
     WgradOut out[2][2];
     float* gb[2];
@@ -35,10 +39,25 @@ struct Wgrad8Args {
 };
 constexpr int kWg8MaxLoads = 10;   // data loads per wave and k-step: 2 (NT + KT) pieces over 4 waves (+ 1 for scale bytes)
 
+// Bytes of one (block of 32 samples, tile) piece: e4m3 / e2m3.  The k-step of a segment (2 x tiles pieces) is one
+// contiguous byte range in memory and is copied as it stands, in chunks of 1 KiB (16 bytes per lane), the last one
+// 512 bytes (32 lanes) when the range is an odd number of half KiB: a launch is bound by the number of such copies a
+// compute unit can have in flight, so 768-byte pieces moved one per copy would gain nothing (and the 12-byte form of
+// global_load_lds is slower still, and writes at a 16-byte stride: tools/microbench/lds_dma12.hip).
+constexpr unsigned kPiece8 = 1024, kPiece6 = 768;
+__device__ __host__ constexpr int seg_chunks(int tiles, unsigned piece) { return (int)((2u * tiles * piece + 1023u) / 1024u); }
+
 __device__ __forceinline__ v8i lds_operand(LDS_AS const char* lo_piece, LDS_AS const char* hi_piece, int lane) {
     const u32x4 lo = *(LDS_AS const u32x4*)(lo_piece + lane * 16);
     const u32x4 hi = *(LDS_AS const u32x4*)(hi_piece + lane * 16);
     return (v8i){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+}
+// e2m3 operand: the 24 bytes of row n of the piece of this lane's sample block (8-byte aligned: three 64-bit reads)
+__device__ __forceinline__ v8i lds_operand6(LDS_AS const char* piece, int n) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    LDS_AS const u32x2* p = (LDS_AS const u32x2*)(piece + n * 24);
+    const u32x2 a = p[0], b = p[1], c = p[2];
+    return (v8i){(int)a[0], (int)a[1], (int)b[0], (int)b[1], (int)c[0], (int)c[1], 0, 0};
 }
 
 // GS > 0: exactly GS data loads per wave and k-step (the host checks); GS = 0: any count up to kWg8MaxLoads.
@@ -50,10 +69,28 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave / a.WK, wk = wave % a.WK;
-    const int C = a.NT + a.KT;                      // tiles per sample block, dY tiles first
-    const int P = 2 * C;                            // data pieces per k-step: [block parity s][tile c]
+    // a slot of the ring: the k-step ranges of the segments dY 0, dY 1, X 0, X 1 (each [block parity][tile][piece]),
+    // then, on the next KiB boundary, 1 KiB of scale bytes [dY segment][parity][256 B]
+    int seg_tiles[4] = {a.A[0].tiles, a.A[1].tiles, a.B[0].tiles, a.B[1].tiles};
+    unsigned seg_base[4];
+    int seg_first[5];                               // first chunk of the segment in the k-step's list of copies
+    {
+        unsigned off = 0;
+        int first = 0;
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            const unsigned piece = sg < 2 ? kPiece6 : kPiece8;
+            seg_base[sg] = off;
+            seg_first[sg] = first;
+            off += 2u * seg_tiles[sg] * piece;
+            first += seg_chunks(seg_tiles[sg], piece);
+        }
+        seg_first[4] = first;
+    }
+    const int P = seg_first[4];                     // copies per k-step
     const int G = GS > 0 ? GS : (P + 3) / 4;        // data loads per wave per k-step
-    const unsigned slot_bytes = (unsigned)(P + 1) * 1024;           // + 1 KiB: [segment][parity][256 B] scale bytes
+    const unsigned sc_base = (seg_base[3] + 2u * seg_tiles[3] * kPiece8 + 1023u) & ~1023u;
+    const unsigned slot_bytes = sc_base + 1024;
     LDS_AS char* ring = (LDS_AS char*)smem;
     const int depth = a.depth;
     LDS_AS char* scratch = ring + depth * slot_bytes + wave * 1024; // landing zone of this wave's padding loads
@@ -72,31 +109,29 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
     const v8i ones = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};
 
     // Per-load source (wave-uniform, scalar registers): a pointer that runs along the k-steps of this workgroup and
-    // its increment.  Load g moves piece p = 4 g + wave: sample-block parity s = p / C, tile c = p % C.
+    // its increment.  Load g moves copy p = 4 g + wave of the k-step's list.
     const char* ld_ptr[GM];
-    unsigned ld_inc[GM];
-    unsigned ld_real = 0;
+    unsigned ld_inc[GM], ld_dst[GM];
+    unsigned ld_real = 0, ld_half = 0;              // bit g: load g moves a real chunk / a 512-byte tail (32 lanes)
 #pragma unroll
     for (int g = 0; g < GM; ++g) {
         const int p = g * 4 + wave;
         const bool real = g < G && p < P;
-        const int sp = p >= C ? 1 : 0, c = p - sp * C;
-        const bool xside = c >= a.NT;
-        const int t = xside ? c - a.NT : c;
-        const WgradSeg s0 = xside ? a.B[0] : a.A[0], s1 = xside ? a.B[1] : a.A[1];
-        const bool second = t >= s0.tiles;
-        const WgradSeg sg = second ? s1 : s0;
-        const int lt = second ? t - s0.tiles : t;
-        const int64_t step = (int64_t)2 * sg.tiles * 1024;          // bytes per k-step of this segment
-        ld_ptr[g] = real ? (const char*)sg.p + q0 * step + ((int64_t)sp * sg.tiles + lt) * 1024 : (const char*)a.A[0].p;
-        ld_inc[g] = real ? (unsigned)(step * qstride) : 0u;
+        const int sg = p >= seg_first[3] ? 3 : p >= seg_first[2] ? 2 : p >= seg_first[1] ? 1 : 0;
+        const int ci = p - seg_first[sg];
+        const char* base = (const char*)(sg == 0 ? a.A[0].p : sg == 1 ? a.A[1].p : sg == 2 ? a.B[0].p : a.B[1].p);
+        const unsigned step = 2u * seg_tiles[sg] * (sg < 2 ? kPiece6 : kPiece8);     // bytes per k-step of this segment
+        ld_ptr[g] = real ? base + q0 * (int64_t)step + (int64_t)ci * 1024 : (const char*)a.A[0].p;
+        ld_inc[g] = real ? (unsigned)((int64_t)step * qstride) : 0u;
+        ld_dst[g] = seg_base[sg] + (unsigned)ci * 1024;
         ld_real |= real ? 1u << g : 0u;
+        ld_half |= (real && (unsigned)(ci + 1) * 1024 > step) ? 1u << g : 0u;
     }
     // scale bytes: wave w fetches the 256 B of (dY segment w >> 1, block parity w & 1)
     const bool sc_real = a.A[wave >> 1].tiles > 0 && a.Asc[wave >> 1] != nullptr;
     const char* sc_ptr = sc_real ? (const char*)a.Asc[wave >> 1] + q0 * 512 + (wave & 1) * 256 : (const char*)a.A[0].p;
     const unsigned sc_inc = sc_real ? (unsigned)(512 * qstride) : 0u;
-    const unsigned sc_dst = (unsigned)P * 1024 + wave * 256;
+    const unsigned sc_dst = sc_base + wave * 256;
 
     int fill = 0, drain = 0;
     LDS_AS char* is_slot = ring;
@@ -110,9 +145,10 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
         constexpr int g = decltype(gc)::value;
         if (GS > 0 || g < G) {
             const bool real = is_live && ((ld_real >> g) & 1u);
-            LDS_AS char* dst = real ? is_slot + (unsigned)(g * 4 + wave) * 1024 : scratch;
+            LDS_AS char* dst = real ? is_slot + ld_dst[g] : scratch;
             const char* src = is_live ? ld_ptr[g] : (const char*)a.A[0].p;       // past the end: a harmless address
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + lane * 16), (LDS_AS void*)dst, 16, 0, 0);
+            if (lane < 32 || !((ld_half >> g) & 1u))        // (a tail chunk ends after lane 31's 16 bytes)
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + lane * 16), (LDS_AS void*)dst, 16, 0, 0);
             ld_ptr[g] += is_live ? ld_inc[g] : 0u;
         }
     };
@@ -133,8 +169,8 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
         int nt = wn * NTW + ii;
         if (nt >= a.NT) nt = 0;
         const int seg = nt >= a.A[0].tiles ? 1 : 0, lt = seg ? nt - a.A[0].tiles : nt;
-        a_off[ii] = (unsigned)nt * 1024;
-        a_sc[ii] = (unsigned)P * 1024 + seg * 512 + kh * 256 + n_lo * 8 + lt;      // this lane supplies block 2Q + kh
+        a_off[ii] = seg_base[seg] + (unsigned)(kh * seg_tiles[seg] + lt) * kPiece6;      // this lane holds, and scales, block 2Q + kh
+        a_sc[ii] = sc_base + seg * 512 + kh * 256 + n_lo * 8 + lt;
     }
     // the (at most two) tiles whose column sums this wave takes: wk and wk + WK of its row
     unsigned b_off[2], b_sc[2];
@@ -148,11 +184,19 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
         if (!b_valid[s]) nt = 0;
         b_tile[s] = nt;
         const int seg = nt >= a.A[0].tiles ? 1 : 0, lt = seg ? nt - a.A[0].tiles : nt;
-        b_off[s] = (unsigned)nt * 1024;
-        b_sc[s] = (unsigned)P * 1024 + seg * 512 + kh * 256 + n_lo * 8 + lt;
+        b_off[s] = seg_base[seg] + (unsigned)(kh * seg_tiles[seg] + lt) * kPiece6;
+        b_sc[s] = sc_base + seg * 512 + kh * 256 + n_lo * 8 + lt;
     }
-    const unsigned hi_off = (unsigned)C * 1024;     // the same tile of the second sample block
-    const unsigned x_off = (unsigned)a.NT * 1024;
+    // the owned output columns (X tiles): the tile's piece of sample block 2Q, and of 2Q + 1
+    unsigned x_lo[KTW], x_hi[KTW];
+#pragma unroll
+    for (int j = 0; j < KTW; ++j) {
+        int kt = wk * KTW + j;
+        if (kt >= a.KT) kt = 0;
+        const int seg = kt >= a.B[0].tiles ? 1 : 0, lt = seg ? kt - a.B[0].tiles : kt;
+        x_lo[j] = seg_base[2 + seg] + (unsigned)lt * kPiece8;
+        x_hi[j] = x_lo[j] + (unsigned)seg_tiles[2 + seg] * kPiece8;
+    }
 
     for (int i = 0; i < depth - 1; ++i) {
         begin_issue(i);
@@ -168,18 +212,14 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
         int SA[NTW], SAb[2];
 #pragma unroll
         for (int ii = 0; ii < NTW; ++ii) {
-            A[ii] = lds_operand(slot + a_off[ii], slot + hi_off + a_off[ii], lane);
+            A[ii] = lds_operand6(slot + a_off[ii], n_lo);
             SA[ii] = *(LDS_AS const unsigned char*)(slot + a_sc[ii]);
         }
 #pragma unroll
-        for (int j = 0; j < KTW; ++j) {
-            int kt = wk * KTW + j;
-            if (kt >= a.KT) kt = 0;
-            B[j] = lds_operand(slot + x_off + kt * 1024, slot + hi_off + x_off + kt * 1024, lane);
-        }
+        for (int j = 0; j < KTW; ++j) B[j] = lds_operand(slot + x_lo[j], slot + x_hi[j], lane);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            Ab[s] = lds_operand(slot + b_off[s], slot + hi_off + b_off[s], lane);
+            Ab[s] = lds_operand6(slot + b_off[s], n_lo);
             SAb[s] = *(LDS_AS const unsigned char*)(slot + b_sc[s]);
         }
         begin_issue(i + depth - 1);
@@ -192,11 +232,11 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
             });
 #pragma unroll
             for (int j = 0; j < KTW; ++j)
-                acc[ii][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[ii], B[j], acc[ii][j], 0, 0, 0, SA[ii], 0, 127);
+                acc[ii][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[ii], B[j], acc[ii][j], 2, 0, 0, SA[ii], 0, 127);
             __builtin_amdgcn_sched_barrier(0);
         });
-        accb[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Ab[0], ones, accb[0], 0, 0, 0, SAb[0], 0, 127);
-        accb[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Ab[1], ones, accb[1], 0, 0, 0, SAb[1], 0, 127);
+        accb[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Ab[0], ones, accb[0], 2, 0, 0, SAb[0], 0, 127);
+        accb[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Ab[1], ones, accb[1], 2, 0, 0, SAb[1], 0, 127);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS write may outlive the workgroup
 
@@ -334,22 +374,29 @@ static bool wgrad8_config(int NT, int KT, int* WN, int* WK, int* tn, int* tk) {
     return *tn != 0;
 }
 
+// 1 KiB copies per k-step (the last one of a segment may be half): see seg_chunks
+static int wgrad8_copies(int a0, int a1, int b0, int b1) {
+    return seg_chunks(a0, kPiece6) + seg_chunks(a1, kPiece6) + seg_chunks(b0, kPiece8) + seg_chunks(b1, kPiece8);
+}
+
 // Instantiations with a compile-time load count: the launches of the 8 x 256 network (colour width 128) and of the
 // SAR network (hidden 156, colour width 180).
 static int wgrad8_static_loads(int tn, int tk, int loads) {
-    static const int kStatic[10][3] = {{4, 4, 8}, {2, 2, 5}, {4, 5, 9}, {5, 3, 7}, {1, 1, 3},
-                                       {3, 3, 5}, {3, 3, 6}, {4, 4, 7}, {2, 2, 3}, {1, 2, 4}};
+    static const int kStatic[9][3] = {{4, 4, 7}, {2, 2, 4}, {4, 5, 8}, {5, 3, 7}, {1, 1, 3},
+                                      {3, 3, 5}, {4, 4, 6}, {2, 2, 3}, {1, 2, 4}};
     for (const auto& v : kStatic)
         if (v[0] == tn && v[1] == tk && v[2] == loads) return loads;
     return 0;
 }
 
-// Which mlp_wgrad8_kernel<tn, tk, gs> instantiation an e4m3 launch with these total padded feature counts uses.
-extern "C" int nerf_mlp_wgrad8_config(int n_feat, int k_feat, int* tn, int* tk, int* gs) {
+// Which mlp_wgrad8_kernel<tn, tk, gs> instantiation a launch with these padded feature counts (two dY segments, two X
+// segments; 0 = segment absent) uses.
+extern "C" int nerf_mlp_wgrad8_config(int n_feat0, int n_feat1, int k_feat0, int k_feat1, int* tn, int* tk, int* gs) {
     int wn, wk;
-    NERF_REQUIRE(tn && tk && gs && n_feat > 0 && k_feat > 0 && n_feat % 32 == 0 && k_feat % 32 == 0);
-    if (!wgrad8_config(n_feat / 32, k_feat / 32, &wn, &wk, tn, tk)) return NERF_ERR_SIZE;
-    *gs = wgrad8_static_loads(*tn, *tk, (2 * (n_feat / 32 + k_feat / 32) + 3) / 4);
+    NERF_REQUIRE(tn && tk && gs && n_feat0 > 0 && k_feat0 > 0 && n_feat1 >= 0 && k_feat1 >= 0);
+    NERF_REQUIRE(n_feat0 % 32 == 0 && n_feat1 % 32 == 0 && k_feat0 % 32 == 0 && k_feat1 % 32 == 0);
+    if (!wgrad8_config((n_feat0 + n_feat1) / 32, (k_feat0 + k_feat1) / 32, &wn, &wk, tn, tk)) return NERF_ERR_SIZE;
+    *gs = wgrad8_static_loads(*tn, *tk, (wgrad8_copies(n_feat0 / 32, n_feat1 / 32, k_feat0 / 32, k_feat1 / 32) + 3) / 4);
     return NERF_OK;
 }
 
@@ -371,24 +418,25 @@ int nerf_wgrad8_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint
     a.nblk = ((n_samples + 255) / 256) * 4;
     int tn = 0, tk = 0;
     if (!wgrad8_config(a.NT, a.KT, &a.WN, &a.WK, &tn, &tk)) return NERF_ERR_SIZE;
-    const int pieces = 2 * (a.NT + a.KT), loads = (pieces + 3) / 4;
+    const int copies = wgrad8_copies(a.A[0].tiles, a.A[1].tiles, a.B[0].tiles, a.B[1].tiles), loads = (copies + 3) / 4;
     if (loads > kWg8MaxLoads) return NERF_ERR_SIZE;
     // as deep a ring as the LDS allows (4 KiB of it is the landing zone of padding loads), within the 6-bit vmcnt
-    a.depth = (kWgradLds / 1024 - 4) / (pieces + 1);
+    const int slot = ((2 * (a.NT * (int)kPiece6 + a.KT * (int)kPiece8) + 1023) & ~1023) + 1024;
+    a.depth = (kWgradLds - 4096) / slot;
     if (a.depth > 6) a.depth = 6;
     if ((a.depth - 2) * (loads + 1) > 63) a.depth = 63 / (loads + 1) + 2;
     if (a.depth < 3) return NERF_ERR_SIZE;
     unsigned grid = grid_hint > 0 ? (unsigned)grid_hint : 256u;
     if ((int64_t)grid > a.nblk) grid = (unsigned)a.nblk;
-    const size_t lds = (size_t)(a.depth * (pieces + 1) + 4) * 1024;
+    const size_t lds = (size_t)a.depth * slot + 4096;
     const int gs = wgrad8_static_loads(tn, tk, loads);
     // two-stage flush when the caller lends a workspace that holds every workgroup's partial tiles and the output
     // is large enough for the atomics to matter
     const int64_t need = (int64_t)grid * 4 * (tn * tk + 2) * 1024 * 4;
     a.partial = (d->workspace != nullptr && d->workspace_bytes >= need && tn * tk >= 4) ? (float*)d->workspace : nullptr;
 #define NERF_W8S(n_, k_, g_) if (tn == n_ && tk == k_ && gs == g_) return launch_wgrad8<n_, k_, g_>(a, grid, lds, st);
-    NERF_W8S(4, 4, 8) NERF_W8S(2, 2, 5) NERF_W8S(4, 5, 9) NERF_W8S(5, 3, 7) NERF_W8S(1, 1, 3)
-    NERF_W8S(3, 3, 5) NERF_W8S(3, 3, 6) NERF_W8S(4, 4, 7) NERF_W8S(2, 2, 3) NERF_W8S(1, 2, 4)
+    NERF_W8S(4, 4, 7) NERF_W8S(2, 2, 4) NERF_W8S(4, 5, 8) NERF_W8S(5, 3, 7) NERF_W8S(1, 1, 3)
+    NERF_W8S(3, 3, 5) NERF_W8S(4, 4, 6) NERF_W8S(2, 2, 3) NERF_W8S(1, 2, 4)
 #undef NERF_W8S
 #define NERF_W8(n_, k_) if (tn == n_ && tk == k_) return launch_wgrad8<n_, k_, 0>(a, grid, lds, st);
     NERF_W8(1, 1) NERF_W8(1, 2) NERF_W8(2, 2) NERF_W8(2, 3) NERF_W8(3, 3) NERF_W8(4, 4) NERF_W8(4, 5) NERF_W8(5, 3) NERF_W8(5, 4)

@@ -34,7 +34,7 @@ class WgradDesc(ctypes.Structure):
 
 _lib.register('nerf_mlp_wgrad_multi', c_int, [POINTER(WgradDesc), c_int64, c_int, _P])
 _lib.register('nerf_mlp_wgrad_config', c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)])
-_lib.register('nerf_mlp_wgrad8_config', c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)])
+_lib.register('nerf_mlp_wgrad8_config', c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)])
 _lib.register('nerf_mlp_wgrad', c_int, [_P, c_int, _P, c_int, c_int64, _P, c_int, c_int, c_int, c_int, _P, c_int, _P])
 
 STREAMED = (['density_net0.%d' % i for i in (0, 2, 4, 6)] + ['density_net1.%d' % i for i in (0, 2, 4, 6)]
@@ -181,10 +181,11 @@ def _wgrad_plan(pk):
 
 def _wgrad_launch_bytes(pk, dsegs, xsegs):
     """Operand bytes per sample that one weight-gradient launch reads."""
-    feats = sum(s[1] for s in dsegs) + sum(s[1] for s in xsegs)
+    dfeats, xfeats = sum(s[1] for s in dsegs), sum(s[1] for s in xsegs)
     if pk.fmt == 0:
-        return 2.0 * feats
-    return 1.0 * feats + 8.0 * len(dsegs)           # e4m3 + 256 scale bytes per 32-sample block and dY segment
+        return 2.0 * (dfeats + xfeats)
+    # e4m3 activations, e2m3 gradients + 256 scale bytes per 32-sample block and dY segment
+    return 1.0 * xfeats + 0.75 * dfeats + 8.0 * len(dsegs)
 
 
 def _param_versions(model):
@@ -244,10 +245,11 @@ def act_block_bytes(pk):
 
 
 def dy_block_bytes(pk):
-    """Bytes per block of 64 samples of each dY buffer of the backward chain (None = unused); in the e4m3 format 12
+    """Bytes per block of 64 samples of each dY buffer of the backward chain (None = unused); in the 8/6-bit format 12
     more entries: the scale bytes of each (8 bytes per feature row and 32-sample block)."""
     tiles = [pk.HT] * 9 + [pk.WT, 1 if pk.view else 0, 1]
-    per = [t * (4096 >> pk.fmt) if (i != 8 and t > 0) else None for i, t in enumerate(tiles)]
+    piece = 1536 if pk.fmt else 4096                # per tile and 64 samples: e2m3 (2 x 768 B) or bf16
+    per = [t * piece if (i != 8 and t > 0) else None for i, t in enumerate(tiles)]
     if pk.fmt:
         per += [512 if b is not None else None for b in per[:12]]
     return per
@@ -310,11 +312,13 @@ WGRAD_GRID = 0          # workgroups per weight-gradient launch; 0 = one per com
 
 
 def wgrad_kernel_name(n_feat, k_feat, fmt=0):
-    """Symbol of the kernel instantiation that handles these feature counts."""
+    """Symbol of the kernel instantiation that handles these feature counts (ints, or for the 8/6-bit format pairs:
+    the padded features of the launch's two dY segments and of its two X segments)."""
     key = (n_feat, k_feat, fmt)
     if key not in _WGRAD_KERNEL and fmt:
+        (n0, n1), (k0, k1) = [(v, 0) if isinstance(v, int) else (tuple(v) + (0,))[:2] for v in (n_feat, k_feat)]
         tn, tk, gs = c_int(), c_int(), c_int()
-        check(lib().nerf_mlp_wgrad8_config(n_feat, k_feat, ctypes.byref(tn), ctypes.byref(tk), ctypes.byref(gs)))
+        check(lib().nerf_mlp_wgrad8_config(n0, n1, k0, k1, ctypes.byref(tn), ctypes.byref(tk), ctypes.byref(gs)))
         _WGRAD_KERNEL[key] = 'mlp_wgrad8_kernel<%d, %d, %d>' % (tn.value, tk.value, gs.value)
     if key not in _WGRAD_KERNEL:
         nw, tn, tk, gt = c_int(), c_int(), c_int(), c_int()
@@ -410,6 +414,8 @@ def _wgrad_launches(pk, acts, dys, n_samples, grads):
                     if blk[0] == '_g98':        # this block stands for rgb_net0's weight gradient as well
                         flops += 2.0 * pk.H * pk.H * n_samples
         nf_all, kf_all = sum(s[1] for s in dsegs), sum(s[1] for s in xsegs)
+        if pk.fmt:      # (the instantiation depends on the split into segments)
+            nf_all, kf_all = tuple(s[1] for s in dsegs), tuple(s[1] for s in xsegs)
         # algorithmic work of the launch: every operand byte once, 2 FLOP per true multiply-add
         with profiling.timed(wgrad_kernel_name(nf_all, kf_all, pk.fmt), flops=flops,
                              bytes_=_wgrad_launch_bytes(pk, dsegs, xsegs) * n_samples):

@@ -43,5 +43,6 @@ for k, item in enumerate(plan):
     nbytes = mlp_bf16._wgrad_launch_bytes(pk, item[0], item[1]) * M
     tot_ms, tot_b = tot_ms + ms, tot_b + nbytes
     nf, kf = sum(s[1] for s in item[0]), sum(s[1] for s in item[1])
-    print(f'launch {k} ({nf:3d} x {kf:3d}) {mlp_bf16.wgrad_kernel_name(nf, kf, pk.fmt):32s} {ms:7.3f} ms {nbytes / ms / 1e6:7.0f} GB/s', flush=True)
+    segs = (tuple(s[1] for s in item[0]), tuple(s[1] for s in item[1])) if pk.fmt else (nf, kf)
+    print(f'launch {k} ({nf:3d} x {kf:3d}) {mlp_bf16.wgrad_kernel_name(*segs, pk.fmt):32s} {ms:7.3f} ms {nbytes / ms / 1e6:7.0f} GB/s', flush=True)
 print(f'all launches: {tot_ms:.3f} ms, {tot_b / tot_ms / 1e6:.0f} GB/s')

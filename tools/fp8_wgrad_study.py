@@ -45,6 +45,24 @@ def e4m3_block_scaled(x, block=32):
     return q.reshape(-1, F)[:M]
 
 
+def e2m3_block_scaled(x, block=32):
+    """Round to OCP e2m3 (fp6: 1.0 .. 7.5 in three binades of eight steps, multiples of 0.125 below 1) after scaling
+    each (column, block of `block` rows) by the power of two that puts its largest magnitude into [4, 8) -- the MX
+    convention; magnitudes between 7.5 and 8 saturate at 7.5."""
+    M, F = x.shape
+    pad = (-M) % block
+    xp = torch.cat([x, x.new_zeros(pad, F)]) if pad else x
+    xb = xp.reshape(-1, block, F)
+    amax = xb.abs().amax(dim=1, keepdim=True)
+    scale = torch.exp2(2.0 - torch.floor(torch.log2(amax.clamp_min(1e-30))))
+    scale = torch.where(amax > 0, scale, torch.ones_like(scale))
+    v = xb * scale
+    mag = v.abs()
+    step = torch.exp2(torch.floor(torch.log2(mag.clamp_min(1.0))) - 3.0)        # 0.125 below 2, 0.25 below 4, 0.5 above
+    q = (torch.round(mag / step) * step).clamp(max=7.5) * torch.sign(v) / scale
+    return q.reshape(-1, F)[:M]
+
+
 def fro(a, b):
     return float((a - b).norm() / b.norm())
 
@@ -58,6 +76,7 @@ def main():
     fx = load_golden('nerf_e2e_c3_1k')
     cfg = cfg_from(fx)
     cfg.mlp_precision = 'bf16'
+    cfg.wgrad_operands = 'bf16'          # the study decodes 16-bit copies
     cfg.level_samples = [int(v) for v in fx['levels']]
     m = MipNeRF(cfg).cuda().train()
     m.load_state_dict(O.init_params(cfg, seed=int(fx['wseed'])), strict=False)
@@ -75,8 +94,8 @@ def main():
     DY = {i: tfrag_dense(st.dys[i], 32 * pk.HT, M) for i in range(8)}
     names = mlp_bf16.STREAMED[:8]
     ins = [E, X[0], X[1], X[2], torch.cat([X[3], E], 1), X[4], X[5], X[6]]
-    print('%-16s %9s | %9s %9s %9s | vs bf16-operand dW: %8s %8s %8s' % ('layer', 'kernel', 'ref:bf16', 'ref:X8', 'ref:X8dY8',
-                                                                         'X e4m3', 'dY mx8', 'both'))
+    print('%-16s %9s | %9s %9s %9s | vs bf16-operand dW: %8s %8s %8s %8s %8s %8s' % (
+        'layer', 'kernel', 'ref:bf16', 'ref:X8', 'ref:X8dY8', 'X e4m3', 'dY mx8', 'both', 'dY mx6', 'X8 dY6', 'X6 dY6'))
     for i, nm in enumerate(names):
         dy, x = DY[i], ins[i]
         base = dy.t() @ x
@@ -86,9 +105,11 @@ def main():
         vb = e4m3_block_scaled(dy).t() @ e4m3(x)
         ref = T(fx['gsample_' + nm + '.weight']).cuda()
         samp = lambda g: g.reshape(-1)[::max(1, g.numel() // 4096)][:4096]
-        print('%-16s %9.2e | %9.4f %9.4f %9.4f | %27.4f %8.4f %8.4f' % (
+        y6 = e2m3_block_scaled(dy)
+        print('%-16s %9.2e | %9.4f %9.4f %9.4f | %27.4f %8.4f %8.4f %8.4f %8.4f %8.4f' % (
             nm, fro(kern, base), fro(samp(base), ref), fro(samp(vx), ref), fro(samp(vb), ref),
-            fro(vx, base), fro(vy, base), fro(vb, base)))
+            fro(vx, base), fro(vy, base), fro(vb, base), fro(y6.t() @ x, base), fro(y6.t() @ e4m3(x), base),
+            fro(y6.t() @ e2m3_block_scaled(x), base)))
 
 
 if __name__ == '__main__':
