@@ -41,7 +41,7 @@ constexpr int kWg8MaxLoads = 10;   // data loads per wave and k-step: 2 (NT + KT
 
 // Bytes of one (block of 32 samples, tile) piece: e4m3 / e2m3.  The k-step of a segment (2 x tiles pieces) is one
 // contiguous byte range in memory and is copied as it stands, in chunks of 1 KiB (16 bytes per lane), the last one
-// 512 bytes (32 lanes) when the range is an odd number of half KiB: a launch is bound by the number of such copies a
+// holding 512 bytes when the range is an odd number of half KiB: a launch is bound by the number of such copies a
 // compute unit can have in flight, so 768-byte pieces moved one per copy would gain nothing (and the 12-byte form of
 // global_load_lds is slower still, and writes at a 16-byte stride: tools/microbench/lds_dma12.hip).
 constexpr unsigned kPiece8 = 1024, kPiece6 = 768;
@@ -82,14 +82,14 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
             const unsigned piece = sg < 2 ? kPiece6 : kPiece8;
             seg_base[sg] = off;
             seg_first[sg] = first;
-            off += 2u * seg_tiles[sg] * piece;
+            off += (unsigned)seg_chunks(seg_tiles[sg], piece) * 1024u;      // (whole KiB: a tail copy's upper lanes land in the gap)
             first += seg_chunks(seg_tiles[sg], piece);
         }
         seg_first[4] = first;
     }
     const int P = seg_first[4];                     // copies per k-step
     const int G = GS > 0 ? GS : (P + 3) / 4;        // data loads per wave per k-step
-    const unsigned sc_base = (seg_base[3] + 2u * seg_tiles[3] * kPiece8 + 1023u) & ~1023u;
+    const unsigned sc_base = seg_base[3] + (unsigned)seg_chunks(seg_tiles[3], kPiece8) * 1024u;
     const unsigned slot_bytes = sc_base + 1024;
     LDS_AS char* ring = (LDS_AS char*)smem;
     const int depth = a.depth;
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
     const unsigned sc_inc = sc_real ? (unsigned)(512 * qstride) : 0u;
     const unsigned sc_dst = sc_base + wave * 256;
 
+    const int lane_off = lane * 16, lane_off_half = (lane & 31) * 16;
     int fill = 0, drain = 0;
     LDS_AS char* is_slot = ring;
     bool is_live = false;
@@ -147,8 +148,10 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
             const bool real = is_live && ((ld_real >> g) & 1u);
             LDS_AS char* dst = real ? is_slot + ld_dst[g] : scratch;
             const char* src = is_live ? ld_ptr[g] : (const char*)a.A[0].p;       // past the end: a harmless address
-            if (lane < 32 || !((ld_half >> g) & 1u))        // (a tail chunk ends after lane 31's 16 bytes)
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + lane * 16), (LDS_AS void*)dst, 16, 0, 0);
+            // (a tail chunk ends after lane 31's 16 bytes: its upper lanes fetch the lower lanes' bytes once more, into
+            // the gap behind the segment; no branch, which would split the block the loads are interleaved in)
+            const int off = ((ld_half >> g) & 1u) ? lane_off_half : lane_off;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + off), (LDS_AS void*)dst, 16, 0, 0);
             ld_ptr[g] += is_live ? ld_inc[g] : 0u;
         }
     };
@@ -210,22 +213,29 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
         drain = drain + 1 == depth ? 0 : drain + 1;
         v8i A[NTW], B[KTW], Ab[2];
         int SA[NTW], SAb[2];
-#pragma unroll
-        for (int ii = 0; ii < NTW; ++ii) {
-            A[ii] = lds_operand6(slot + a_off[ii], n_lo);
-            SA[ii] = *(LDS_AS const unsigned char*)(slot + a_sc[ii]);
-        }
+        // LDS returns in order and one wave per SIMD has nothing else to cover its reads with: the operands of the
+        // first row of products are read first, those of row ii + 1 ahead of the products of row ii, the column-sum
+        // operands ahead of the last row, so that the matrix pipe starts after 9.5 KiB of the wave's 17 and the rest
+        // arrives under it.
+        A[0] = lds_operand6(slot + a_off[0], n_lo);
+        SA[0] = *(LDS_AS const unsigned char*)(slot + a_sc[0]);
 #pragma unroll
         for (int j = 0; j < KTW; ++j) B[j] = lds_operand(slot + x_lo[j], slot + x_hi[j], lane);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            Ab[s] = lds_operand6(slot + b_off[s], n_lo);
-            SAb[s] = *(LDS_AS const unsigned char*)(slot + b_sc[s]);
-        }
         begin_issue(i + depth - 1);
         issue_scales();
         static_for<0, NTW>([&](auto ic) __attribute__((always_inline)) {
             constexpr int ii = decltype(ic)::value;
+            if constexpr (ii + 1 < NTW) {
+                A[ii + 1] = lds_operand6(slot + a_off[ii + 1], n_lo);
+                SA[ii + 1] = *(LDS_AS const unsigned char*)(slot + a_sc[ii + 1]);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    Ab[s] = lds_operand6(slot + b_off[s], n_lo);
+                    SAb[s] = *(LDS_AS const unsigned char*)(slot + b_sc[s]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
             static_for<0, GM>([&](auto gc) __attribute__((always_inline)) {
                 constexpr int g = decltype(gc)::value;
                 if constexpr ((g * NTW) / GM == ii) issue_load(gc);
@@ -421,7 +431,7 @@ int nerf_wgrad8_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint
     const int copies = wgrad8_copies(a.A[0].tiles, a.A[1].tiles, a.B[0].tiles, a.B[1].tiles), loads = (copies + 3) / 4;
     if (loads > kWg8MaxLoads) return NERF_ERR_SIZE;
     // as deep a ring as the LDS allows (4 KiB of it is the landing zone of padding loads), within the 6-bit vmcnt
-    const int slot = ((2 * (a.NT * (int)kPiece6 + a.KT * (int)kPiece8) + 1023) & ~1023) + 1024;
+    const int slot = (copies + 1) * 1024;
     a.depth = (kWgradLds - 4096) / slot;
     if (a.depth > 6) a.depth = 6;
     if ((a.depth - 2) * (loads + 1) > 63) a.depth = 63 / (loads + 1) + 2;
