@@ -175,9 +175,10 @@ def main():
     ap.add_argument('--chunk', type=int, default=65536, help='rays per forward/backward chunk')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--wgrad-operands', default=None, choices=['bf16', 'e4m3'],
-                    help='format of the saved weight-gradient operands (default: the library default, e4m3; the MLP '
-                         'itself computes in bf16 either way)')
+    ap.add_argument('--wgrad-operands', default=None, choices=['bf16', 'mx', 'e4m3'],
+                    help='format of the saved weight-gradient operands (default: the library default, mx = activations '
+                         'e4m3 + gradients block-scaled e2m3, of which e4m3 is the older name; the MLP itself computes in '
+                         'bf16 either way)')
     ap.add_argument('--rehearse-one-gpu', action='store_true',
                     help='N>1 ranks all on cuda:0 over gloo: a rehearsal of the multi-rank code path on a one-GPU box '
                          '(its numbers mean nothing)')
@@ -312,7 +313,7 @@ def main():
                     roof['stores'] = {'achieved': r['bytes'] / (r['ms'] * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                       'frac': r['bytes'] / (r['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       'algorithmic_bytes_per_launch': r['bytes'] / r['calls']}
-            roof.update(avg_launch_ms=avg_ms, launches_per_step=r['calls'] / args.steps, traffic=pmc_traffic(dom, args.rays) if (args.chunk >= args.rays and args.wgrad_operands in (None, mlp_default_operands())) else None)
+            roof.update(avg_launch_ms=avg_ms, launches_per_step=r['calls'] / args.steps, traffic=pmc_traffic(dom, args.rays) if (args.chunk >= args.rays and args.wgrad_operands in (None, 'e4m3', mlp_default_operands())) else None)
             out['roofline'] = roof
             mlp_flops = sum(prof[k]['flops'] for k in prof if k.startswith('mlp_'))
             mlp_ms = sum(prof[k]['ms'] for k in prof if k.startswith('mlp_'))

@@ -260,13 +260,14 @@ int nerf_view_frag(const float* dirs, int64_t n_rays, int min_deg, int max_deg, 
 /* Storage format of the transposed fragments that the chain kernels save for the weight-gradient pass (the chain
  * itself always computes in bf16 with fp32 accumulation):
  *   NERF_TFRAG_BF16  bf16, 128 bytes per sample per 64 features;
- *   NERF_TFRAG_E4M3  OCP e4m3, 64 bytes per sample per 64 features; gradient buffers carry one power-of-two scale
- *                    per (feature, block of 32 samples) in a side array of 8 bytes per sample block and feature row
- *                    (the MX block-scale layout of the matrix cores along the reduction axis), activations are
- *                    stored unscaled.  Halves the bytes the training step moves; the weight gradients differ from
- *                    the bf16-operand ones by 1e-3 .. 7e-3 relative (Frobenius) on a 196 608-sample batch. */
+ *   NERF_TFRAG_MX    OCP microscaling element formats: activations as e4m3 (64 bytes per sample per 64 features,
+ *                    unscaled), gradients as e2m3 (6 bits: 48 bytes per sample per 64 features) with one power-of-two
+ *                    scale per (feature, block of 32 samples) in a side array of 8 bytes per sample block and feature
+ *                    row -- the block-scale layout of the matrix cores along the reduction axis.  The training step
+ *                    moves well under half the bytes; the weight gradients differ from the bf16-operand ones by
+ *                    1e-3 .. 7e-3 relative (Frobenius) on a 196 608-sample batch. */
 #define NERF_TFRAG_BF16 0
-#define NERF_TFRAG_E4M3 1
+#define NERF_TFRAG_MX 1
 
 /* Forward chain for n_samples rows: raw_density[M], raw_rgb[M,3] (after the sigmoid),
  * raw_angle[M,2] (SAR).  Row m takes the view features of ray m / ray_div (NeRF, ray_div = samples
@@ -277,7 +278,7 @@ int nerf_view_frag(const float* dirs, int64_t n_rays, int min_deg, int max_deg, 
  * output is never formed), [10..19] their ReLU sign words (nblk * 2 *
  * ceil(features / 256) * 1024 bytes; [18] unused, may be NULL), [20] / [21] the position encoding and
  * view features as transposed fragments, [22] (SAR only) the trunk output in fragment order (nblk * H_padded
- * * 128 bytes).  With tfrag_fmt = NERF_TFRAG_E4M3 the transposed-fragment buffers [0..9], [20], [21] hold e4m3 and
+ * * 128 bytes).  With tfrag_fmt = NERF_TFRAG_MX the transposed-fragment buffers [0..9], [20], [21] hold e4m3 and
  * need half the bytes.  Without view directions view_frag, [9], [19] and [21] are unused (may be NULL).
  *                                                      reference: model.py:117-132, 343-359 */
 int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const float* consts, const void* enc_frag,
@@ -303,8 +304,8 @@ int nerf_mlp_fwd_composite(const nerf_mlp_dims* dims, const void* wfwd, const fl
  * (model.py:278-302): g_angle [M,2], raw_angle, raw_density (the forward's outputs), ln_stats and the forward
  * constants block are required too; the density head tile then carries rows g*rstd, g*rstd*mean, g, from which
  * the LayerNorm and density-weight gradients are assembled (NeRF: pass NULL for them).  With tfrag_fmt =
- * NERF_TFRAG_E4M3 every dys[i] holds e4m3 (half the bytes) and dys[12 + i] (nblk * 2 * 256 bytes each) receives
- * its scale bytes.  Without view directions there is one head tile, dys[11] (rows: density, rgb 1..3, SAR angle 4..5
+ * NERF_TFRAG_MX every dys[i] holds block-scaled e2m3 (nblk * features * 48 bytes) and dys[12 + i] (nblk * 2 * 256
+ * bytes each) receives its scale bytes.  Without view directions there is one head tile, dys[11] (rows: density, rgb 1..3, SAR angle 4..5
  * and the two LayerNorm sums g*rstd*mean, g in rows 6..7); dys[9], dys[10] are unused (may be NULL).
  *                              reference: autograd of model.py:117-132 (aten::mm, threshold_backward) */
 int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, const float* consts, int64_t n_samples,
@@ -326,7 +327,7 @@ int nerf_mlp_wgrad(const void* dy_tfrag, int n_feat, const void* x_tfrag, int k_
  * [dY of rgb_net0 | dY of final_density] against the trunk output.  Block (i, j) accumulates
  * G[i][j][n, col0[i][j] + k] += sum_m dy[i][m, n] x[j][m, k] for n < dy_true[i], k < x_true[j] (G[i][j] NULL = skip);
  * gb[i][n] += sum_m dy[i][m, n] (nullable).  Feature counts are padded (multiples of 32); unused second
- * segments have feature count 0.  Total dY + X features <= 576; in the e4m3 format a dY segment has <= 256 features.
+ * segments have feature count 0.  Total dY + X features <= 576; in the MX format a dY segment has <= 256 features.
  *                              reference: autograd of nn.Linear (aten::mm of dY^T and X, aten::sum) */
 typedef struct nerf_wgrad_desc {
     const void* dy[2];
@@ -336,9 +337,9 @@ typedef struct nerf_wgrad_desc {
     float* G[2][2];
     int ld[2][2], col0[2][2];
     float* gb[2];
-    int tfrag_fmt;             /* NERF_TFRAG_BF16 or NERF_TFRAG_E4M3: the format of dy[] and x[] */
-    const void* dy_scale[2];   /* NERF_TFRAG_E4M3: the scale bytes of dy[] (what nerf_mlp_bwd wrote beside them) */
-    void* workspace;           /* optional (NERF_TFRAG_E4M3): device scratch for a two-stage flush of the workgroups'
+    int tfrag_fmt;             /* NERF_TFRAG_BF16 or NERF_TFRAG_MX: the format of dy[] and x[] */
+    const void* dy_scale[2];   /* NERF_TFRAG_MX: the scale bytes of dy[] (what nerf_mlp_bwd wrote beside them) */
+    void* workspace;           /* optional (NERF_TFRAG_MX): device scratch for a two-stage flush of the workgroups'
                                 * partial sums instead of float atomics from all of them; 96 MiB covers every shape;
                                 * NULL or too small: atomics.  Its contents mean nothing between calls. */
     int64_t workspace_bytes;
@@ -349,7 +350,7 @@ int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_h
  * counts uses (gt = compile-time loads per wave and k-step, 0 = run-time count), so a profiler can label launches
  * by kernel symbol.  (No reference counterpart: measurement support.) */
 int nerf_mlp_wgrad_config(int n_feat, int k_feat, int* nw, int* tn, int* tk, int* gt);
-/* The same for NERF_TFRAG_E4M3 launches: mlp_wgrad8_kernel<tn, tk, gs> (gs = compile-time data loads per wave and
+/* The same for NERF_TFRAG_MX launches: mlp_wgrad8_kernel<tn, tk, gs> (gs = compile-time data loads per wave and
  * k-step, 0 = run-time count); the count depends on how the features split into the two dY and two X segments of
  * the launch (0 = segment absent). */
 int nerf_mlp_wgrad8_config(int n_feat0, int n_feat1, int k_feat0, int k_feat1, int* tn, int* tk, int* gs);

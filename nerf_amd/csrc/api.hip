@@ -1,7 +1,7 @@
 // ABI version and error strings of libnerf_amd.
 #include "common.h"
 
-extern "C" int nerf_abi_version(void) { return 3; }
+extern "C" int nerf_abi_version(void) { return 4; }
 
 extern "C" const char* nerf_error_string(int code) {
     switch (code) {

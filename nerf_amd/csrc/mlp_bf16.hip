@@ -1637,7 +1637,7 @@ extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const f
     HostDims d;
     NERF_REQUIRE(make_dims(dims, &d) && wfwd && consts && enc_frag && (view_frag || d.V == 0) && raw_density && raw_rgb);
     NERF_REQUIRE(n_samples > 0 && ray_div > 0 && n_rays > 0);
-    NERF_REQUIRE(tfrag_fmt == NERF_TFRAG_BF16 || tfrag_fmt == NERF_TFRAG_E4M3);
+    NERF_REQUIRE(tfrag_fmt == NERF_TFRAG_BF16 || tfrag_fmt == NERF_TFRAG_MX);
     if (d.sar) NERF_REQUIRE(raw_angle != nullptr);
     MlpFwdArgs a;
     a.wfwd = (const bf16x8*)wfwd;
@@ -1669,7 +1669,7 @@ extern "C" int nerf_mlp_fwd(const nerf_mlp_dims* dims, const void* wfwd, const f
     a.act = make_act(nullptr);
 #define X(ht_, wt_, dks_, vks_, sar_)                                                             \
     if (d.HT == ht_ && d.WT == wt_ && d.DKS == dks_ && d.VKS == vks_ && (d.sar != 0) == sar_)     \
-        return (acts && tfrag_fmt == NERF_TFRAG_E4M3)                                             \
+        return (acts && tfrag_fmt == NERF_TFRAG_MX)                                             \
                    ? launch_fwd<Net<ht_, wt_, dks_, vks_, sar_, true>>(a, nerf_stream(stream))    \
                    : launch_fwd<Net<ht_, wt_, dks_, vks_, sar_, false>>(a, nerf_stream(stream));
     NERF_NET_LIST(X)
@@ -1736,16 +1736,16 @@ extern "C" int nerf_mlp_bwd(const nerf_mlp_dims* dims, const void* wbwd, const f
         a.tdy[i] = (bf16x8*)dys[i];
     }
     NERF_REQUIRE((dys[10] || d.V == 0) && dys[11]);
-    NERF_REQUIRE(tfrag_fmt == NERF_TFRAG_BF16 || tfrag_fmt == NERF_TFRAG_E4M3);
+    NERF_REQUIRE(tfrag_fmt == NERF_TFRAG_BF16 || tfrag_fmt == NERF_TFRAG_MX);
     a.tdy_hd = (bf16x8*)dys[10];
     a.tdy_dens = (bf16x8*)dys[11];
     for (int i = 0; i < 12; ++i) {
-        a.tsc[i] = tfrag_fmt == NERF_TFRAG_E4M3 ? dys[12 + i] : nullptr;
-        if (tfrag_fmt == NERF_TFRAG_E4M3) NERF_REQUIRE(a.tsc[i] != nullptr || i == 8 || (d.V == 0 && (i == 9 || i == 10)));
+        a.tsc[i] = tfrag_fmt == NERF_TFRAG_MX ? dys[12 + i] : nullptr;
+        if (tfrag_fmt == NERF_TFRAG_MX) NERF_REQUIRE(a.tsc[i] != nullptr || i == 8 || (d.V == 0 && (i == 9 || i == 10)));
     }
 #define X(ht_, wt_, dks_, vks_, sar_)                                                            \
     if (d.HT == ht_ && d.WT == wt_ && d.DKS == dks_ && d.VKS == vks_ && (d.sar != 0) == sar_)     \
-        return tfrag_fmt == NERF_TFRAG_E4M3                                                       \
+        return tfrag_fmt == NERF_TFRAG_MX                                                       \
                    ? launch_bwd<Net<ht_, wt_, dks_, vks_, sar_, true>>(a, nerf_stream(stream))    \
                    : launch_bwd<Net<ht_, wt_, dks_, vks_, sar_, false>>(a, nerf_stream(stream));
     NERF_NET_LIST(X)
@@ -1808,14 +1808,14 @@ static int launch_wgrad(const WgradArgs& a, unsigned grid, size_t lds, hipStream
 extern "C" int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint, void* stream) {
     if (n_samples == 0) return NERF_OK;
     NERF_REQUIRE(d && n_samples > 0);
-    NERF_REQUIRE(d->tfrag_fmt == NERF_TFRAG_BF16 || d->tfrag_fmt == NERF_TFRAG_E4M3);
+    NERF_REQUIRE(d->tfrag_fmt == NERF_TFRAG_BF16 || d->tfrag_fmt == NERF_TFRAG_MX);
     for (int i = 0; i < 2; ++i) {
         const int nf = d->dy_feat[i], kf = d->x_feat[i];
         NERF_REQUIRE(nf >= 0 && kf >= 0 && nf % 32 == 0 && kf % 32 == 0 && (i == 1 || (nf > 0 && kf > 0)));
         NERF_REQUIRE((nf == 0 || d->dy[i]) && (kf == 0 || d->x[i]) && d->dy_true[i] <= nf && d->x_true[i] <= kf);
     }
     NERF_REQUIRE(d->G[0][0] != nullptr);
-    if (d->tfrag_fmt == NERF_TFRAG_E4M3) return nerf_wgrad8_multi(d, n_samples, grid_hint, nerf_stream(stream));
+    if (d->tfrag_fmt == NERF_TFRAG_MX) return nerf_wgrad8_multi(d, n_samples, grid_hint, nerf_stream(stream));
     WgradArgs a;
     a.NT = a.KT = 0;
     for (int i = 0; i < 2; ++i) {

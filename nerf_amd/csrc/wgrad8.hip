@@ -1,4 +1,4 @@
-// Weight gradients of the fused MLP from microscaling-format operands (NERF_TFRAG_E4M3) for gfx950.
+// Weight gradients of the fused MLP from microscaling-format operands (NERF_TFRAG_MX) for gfx950.
 //
 // G[n][k] += sum_m dY[m][n] X[m][k] and gb[n] += sum_m dY[m][n], operands given as transposed fragments (feature on
 // the lane, samples along the registers; layouts in mlp_bf16.hip): activations X as e4m3 ("T-frag8"), gradients dY as

@@ -41,9 +41,10 @@ STREAMED = (['density_net0.%d' % i for i in (0, 2, 4, 6)] + ['density_net1.%d' %
             + ['rgb_net0.0', 'rgb_net1.0'])
 RAY_SHAPES = {'cone': 0, 'cylinder': 1}
 # Storage format of the weight-gradient operands the chain kernels save (NERF_TFRAG_* of include/nerf_amd.h).
-# `config.wgrad_operands` ('bf16' or 'e4m3') selects it per model; this is the default.
-TFRAG_FORMATS = {'bf16': 0, 'e4m3': 1}
-DEFAULT_WGRAD_OPERANDS = 'e4m3'
+# `config.wgrad_operands` selects it per model: 'bf16' (16-bit copies) or 'mx' (activations e4m3, gradients block-scaled
+# e2m3; 'e4m3' is accepted as the older name of the same setting); this is the default.
+TFRAG_FORMATS = {'bf16': 0, 'mx': 1, 'e4m3': 1}
+DEFAULT_WGRAD_OPERANDS = 'mx'
 
 
 _FOLD_SPLIT_K = 8       # K slices of the small fp32 products around the folded colour layer (few output tiles)

@@ -288,7 +288,7 @@ def block_scaled_e2m3(x):
 
 @pytest.mark.parametrize('tag,kw,S,n', [CASES[0], CASES[1], CASES[3]])
 def test_e4m3_weight_gradient_operands(tag, kw, S, n):
-    """The 8/6-bit form of the saved weight-gradient operands (NERF_TFRAG_E4M3): (1) the activation copies are the
+    """The 8/6-bit form of the saved weight-gradient operands (NERF_TFRAG_MX): (1) the activation copies are the
     e4m3 rounding of the bf16 copies, the gradient copies their block-scaled e2m3 rounding, bit for bit; (2) the
     matrix-core kernel on these operands returns dY^T X of exactly those values (fp32 summation error).
     (How far the gradients move from the bf16-operand ones is measured where the upstream gradients are those of
