@@ -26,7 +26,10 @@ UNITS = {
     'sampling.o': ('sampling.hip', ['-ffp-contract=off']),
     'composite.o': ('composite.hip', ['-ffp-contract=off']),
     'gemm_f32.o': ('gemm_f32.hip', []),
-    'wgrad8.o': ('wgrad8.hip', []),
+    # VGPR-form matrix-core instructions where an accumulator tile lives in the vector registers: the outputs of the
+    # larger launches exceed the 256 accumulation registers, and the default form copies such tiles in and out
+    # of them around every product (layer 4's launch: 1.10 -> 0.86 ms)
+    'wgrad8.o': ('wgrad8.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form']),
 }
 UNITS.update({'mlp_bf16_p%d.o' % p: ('mlp_bf16.hip', ['-DNERF_NET_PART=%d' % p]) for p in range(8)})   # default contraction
 JOBS = int(os.environ.get('MAX_JOBS', '8'))

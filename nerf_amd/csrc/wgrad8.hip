@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
     const unsigned sc_inc = sc_real ? (unsigned)(512 * qstride) : 0u;
     const unsigned sc_dst = sc_base + wave * 256;
 
-    const int lane_off = lane * 16, lane_off_half = (lane & 31) * 16;
+    const int lane_off = lane * 16, lane_off_hi = (lane & 32) * 16;
     int fill = 0, drain = 0;
     LDS_AS char* is_slot = ring;
     bool is_live = false;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad8_kernel(Wgrad8Args a) {
             const char* src = is_live ? ld_ptr[g] : (const char*)a.A[0].p;       // past the end: a harmless address
             // (a tail chunk ends after lane 31's 16 bytes: its upper lanes fetch the lower lanes' bytes once more, into
             // the gap behind the segment; no branch, which would split the block the loads are interleaved in)
-            const int off = ((ld_half >> g) & 1u) ? lane_off_half : lane_off;
+            const int off = lane_off - (lane_off_hi & (int)(0u - ((ld_half >> g) & 1u)));     // (mask arithmetic, not a select)
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + off), (LDS_AS void*)dst, 16, 0, 0);
             ld_ptr[g] += is_live ? ld_inc[g] : 0u;
         }
