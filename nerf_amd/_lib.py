@@ -51,6 +51,8 @@ _SIGS = {
     'nerf_gemm_f32': (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, c_int64, c_int64, c_int, c_int64,
                               c_int, c_int, _P]),
     'nerf_act_bwd_f32': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int, c_int, _P]),
+    'nerf_matmul_small_f32': (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, c_int64, c_int, c_int, c_int,
+                                      c_int, _P]),
     'nerf_colsum_f32': (c_int, [_P, c_int64, c_int64, c_int, _P, _P]),
     'nerf_layernorm_fwd': (c_int, [_P, _P, _P, c_int64, c_int, c_float, _P, _P, _P, _P]),
     'nerf_layernorm_bwd': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P]),

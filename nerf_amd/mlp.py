@@ -32,6 +32,15 @@ def gemm(a, a_strides, b, b_strides, m, n, k, bias=None, act=0, split_k=1, out=N
     return out
 
 
+def matmul_small(a, a_strides, b, b_strides, m, n, k, bias=None, out=None, accumulate=False):
+    """out[m,n] (+)= A[m,k] B[k,n] (+ bias) for small products, in a fixed summation order (no atomics)."""
+    if out is None:
+        out = torch.empty(m, n, device=a.device, dtype=torch.float32)
+    check(lib().nerf_matmul_small_f32(ptr(a), a_strides[0], a_strides[1], ptr(b), b_strides[0], b_strides[1], ptr(bias),
+                                      ptr(out), out.stride(0), m, n, k, int(bool(accumulate)), stream()))
+    return out
+
+
 class _Linear(torch.autograd.Function):
     """y = act(x W^T + b) with W [out,in]; backward = act', dX = dY W, dW = dY^T X, db = colsum(dY)."""
 

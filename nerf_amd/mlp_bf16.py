@@ -10,7 +10,7 @@ import torch
 
 from . import _lib, profiling
 from ._lib import MlpDims, check, f32c, lib, ptr, stream
-from .mlp import gemm
+from .mlp import matmul_small
 
 _P = c_void_p
 _lib.register('nerf_mlp_sizes', c_int, [POINTER(MlpDims), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)])
@@ -47,7 +47,6 @@ TFRAG_FORMATS = {'bf16': 0, 'mx': 1, 'e4m3': 1}
 DEFAULT_WGRAD_OPERANDS = 'mx'
 
 
-_FOLD_SPLIT_K = 8       # K slices of the small fp32 products around the folded colour layer (few output tiles)
 
 
 def _raw(t):
@@ -97,10 +96,10 @@ class Packed:
             self.W8, self.b8 = f32c(p['rgb_net0.0.weight']), f32c(p['rgb_net0.0.bias'])
             self.W9 = f32c(p['rgb_net1.0.weight'])
             fold = self.W9.clone()
-            # (no split-K here: its atomic sums would make the bf16 rounding of the folded matrix vary from one
-            # packing of the same weights to the next)
-            fold[:, :H] = gemm(self.W9, (H + V, 1), self.W8, (H, 1), W, H, H)                        # W9[:, :H] @ W8
-            bias9 = gemm(self.b8, (H, 1), self.W9, (1, H + V), 1, W, H, bias=f32c(p['rgb_net1.0.bias']))[0]  # b8 W9a^T + b9
+            # (a fixed summation order: atomic split-K sums would make the bf16 rounding of the folded matrix vary from
+            # one packing of the same weights to the next)
+            matmul_small(self.W9, (H + V, 1), self.W8, (H, 1), W, H, H, out=fold)                    # W9[:, :H] @ W8
+            bias9 = matmul_small(self.b8, (H, 1), self.W9, (1, H + V), 1, W, H, bias=f32c(p['rgb_net1.0.bias']))[0]  # b8 W9a^T + b9
             tail = [fold, f32c(self.head_density), f32c(self.head_colour)]
         else:
             # one head tile on the trunk output: density row, then the colour (and angle) heads
@@ -341,15 +340,14 @@ def fold_gradients(pk, grads):
     """Gradients of rgb_net0.0 and of rgb_net1.0's trunk columns from what the folded layer's launch produced:
     G = sum_m dY9 x7^T (grads['_g98.weight'], [W,H]) and s = sum_m dY9 (grads['_g98.bias']).  With
     z9 = W9a (W8 x7 + b8) + W9v view + b9:   dW9a = G W8^T + s b8^T,  db9 = s,  dW8 = W9a^T G,  db8 = W9a^T s.
-    Small exact-fp32 products (split-K form: they add into the running gradients)."""
+    Small fp32 products in a fixed summation order; they add into the running gradients."""
     H, W, V = pk.H, pk.W, pk.V
     G, s = grads['_g98.weight'], grads['_g98.bias']
     g9, g8 = grads['rgb_net1.0.weight'], grads['rgb_net0.0.weight']
-    k = _FOLD_SPLIT_K
-    gemm(G, (H, 1), pk.W8, (1, H), W, H, H, split_k=k, out=g9)                        # += G W8^T   (columns 0..H-1)
-    gemm(s, (1, 1), pk.b8, (H, 1), W, H, 1, split_k=2, out=g9)                        # += s b8^T
-    gemm(pk.W9, (1, H + V), G, (H, 1), H, H, W, split_k=k, out=g8)                    # += W9a^T G
-    gemm(pk.W9, (1, H + V), s, (1, 1), H, 1, W, split_k=k, out=grads['rgb_net0.0.bias'].view(H, 1))   # += W9a^T s
+    matmul_small(G, (H, 1), pk.W8, (1, H), W, H, H, out=g9, accumulate=True)          # += G W8^T   (columns 0..H-1)
+    matmul_small(s, (1, 1), pk.b8, (H, 1), W, H, 1, out=g9, accumulate=True)          # += s b8^T
+    matmul_small(pk.W9, (1, H + V), G, (H, 1), H, H, W, out=g8, accumulate=True)      # += W9a^T G
+    matmul_small(pk.W9, (1, H + V), s, (1, 1), H, 1, W, out=grads['rgb_net0.0.bias'].view(H, 1), accumulate=True)   # += W9a^T s
     grads['rgb_net1.0.bias'].add_(s)
 
 
