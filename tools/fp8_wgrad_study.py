@@ -1,11 +1,13 @@
-"""What 8-bit copies of the weight-gradient operands would cost in accuracy, measured on the kernels' own buffers.
+"""What 8- and 6-bit copies of the weight-gradient operands cost in accuracy, measured on the kernels' own buffers.
 
 Runs one fused training step on the 1024-ray fixture (tests/golden/nerf_e2e_c3_1k.npz: 196 608 samples, 8x256
 network), unpacks the saved activations X and the gradients dY from their transposed-fragment buffers and forms
 dW = dY^T X per trunk layer in fp32 from: the bf16 operands as stored (what the kernels compute), X rounded to OCP
 e4m3, dY rounded to e4m3 with one power-of-two scale per (feature, 32-sample block) (the MX block-scale layout
-along the reduction axis), both.  Prints the relative Frobenius error of each variant against the bf16-operand dW
-and the error of each against the reference's fp32 gradient sample stored in the fixture.
+along the reduction axis), both; dY rounded to block-scaled e2m3 (what the training step stores), with X in e4m3
+(what it stores) and with X in block-scaled e2m3 as well.  Prints the relative Frobenius error of each variant against
+the bf16-operand dW and the error of the first three against the reference's fp32 gradient sample stored in the
+fixture.
 """
 import os
 import sys
