@@ -111,3 +111,22 @@ def test_scatter_op_equals_the_autograd_wrapper():
     torch.library.opcheck(torch.ops.nerf_amd.scatter.default,
                           (rgb.clone().requires_grad_(True), ang, den, power, t, d, bins, 40.0, False, 0.0, 0.0),
                           test_utils=('test_schema', 'test_autograd_registration', 'test_faketensor'))
+
+
+@pytest.mark.gpu
+def test_matmul_small_fixed_order_product():
+    """nerf_matmul_small_f32 (the weight-fold products): strided / transposed operands, bias, accumulation; fp64 torch as
+    the reference (1e-6), and the same bits on repeated calls."""
+    from nerf_amd.mlp import matmul_small
+    g = torch.Generator().manual_seed(11)
+    m, n, k = 37, 53, 129
+    A = torch.randn(m, k + 5, generator=g).cuda()            # row stride k + 5
+    Bt = torch.randn(n, k, generator=g).cuda()               # B given transposed
+    bias = torch.randn(n, generator=g).cuda()
+    want = (A[:, :k].double() @ Bt.double().t() + bias.double()).float()
+    out = matmul_small(A, (k + 5, 1), Bt, (1, k), m, n, k, bias=bias)
+    assert float((out - want).abs().max() / want.abs().max()) < 1e-6
+    assert torch.equal(out, matmul_small(A, (k + 5, 1), Bt, (1, k), m, n, k, bias=bias))
+    big = torch.ones(m, n + 3, device='cuda')                # accumulate into a wider matrix's first n columns
+    matmul_small(A, (k + 5, 1), Bt, (1, k), m, n, k, out=big, accumulate=True)
+    assert float((big[:, :n] - 1 - (want - bias)).abs().max() / want.abs().max()) < 1e-6 and bool((big[:, n:] == 1).all())
