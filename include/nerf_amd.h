@@ -167,7 +167,10 @@ int nerf_scatter_fwd(const float* rgb, const float* angle, const float* density,
  * no counterpart in the reference; it is for callers that cannot allocate: code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc.  Limits: n_rays <= 65536 and nsam <= 65536, else NERF_ERR_SIZE.
  * Same outputs as nerf_scatter_fwd (ray_bin and comp remain caller buffers: the backward pass reads them).  Every
- * call on a GPU uses that GPU's one array: calls that overlap on one GPU (two streams, two threads) race. */
+ * call on a GPU uses that GPU's one array: calls that overlap on one GPU (two streams, two threads) race.
+ * The first call on each device looks the array's address up (hipGetSymbolAddress: a module lookup, not a stream
+ * operation); make that one call outside any stream capture, on every device that will capture -- later calls only
+ * enqueue two memsets and two kernels and may be captured (tests/test_zz_no_alloc.py replays such a graph). */
 int nerf_scatter_fwd_static(const float* rgb, const float* angle, const float* density, const float* power,
                             const float* t_vals, const float* dirs, const float* pulse_bins, int64_t n_rays,
                             int num_samples, int nsam, float wavelength, const nerf_activation* act,

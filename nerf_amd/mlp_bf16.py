@@ -55,24 +55,55 @@ def _raw(t):
     return c_void_p(t.data_ptr())
 
 
-class Packed:
-    """bf16 weight streams + fp32 constants of one model, valid until the next optimizer step."""
+class Geom:
+    """Layer sizes of one network and the format of its saved weight-gradient operands: everything the buffer sizes
+    depend on.  `ints()` / `from_ints` carry it through a custom op's integer-list argument."""
 
-    def __init__(self, model, need_bwd=True):
+    def __init__(self, D, V, H, W, sar, fmt):
+        self.D, self.V, self.H, self.W, self.sar, self.fmt = int(D), int(V), int(H), int(W), bool(sar), int(fmt)
+        self.view = self.V > 0                      # without view directions (model.py:78-92, 283-302) no colour layer
+        self.HT, self.WT = (self.H + 31) // 32, (self.W + 31) // 32
+        self.DKS, self.VKS = (self.D + 15) // 16, (self.V + 15) // 16
+        self.DT, self.VT = (self.DKS + 1) // 2, (self.VKS + 1) // 2
+
+    @property
+    def dims(self):
+        """nerf_mlp_dims of the C ABI (built on use: a compiler tracing through this class never meets ctypes)."""
+        return MlpDims(self.D, self.V, self.H, self.W, int(self.sar))
+
+    @staticmethod
+    def of_model(model):
         cfg = model.config
-        p = {k: v.detach() for k, v in model.named_parameters()}
+        view = hasattr(model, 'rgb_net0')
+        return Geom(6 * (cfg.max_deg - cfg.min_deg), 3 + 6 * (cfg.viewdirs_max_deg - cfg.viewdirs_min_deg) if view else 0,
+                    cfg.hidden, cfg.num_samples if view else 0, hasattr(model, 'final_angle'),
+                    TFRAG_FORMATS[getattr(cfg, 'wgrad_operands', None) or DEFAULT_WGRAD_OPERANDS])
+
+    def ints(self):
+        return [self.D, self.V, self.H, self.W, int(self.sar), self.fmt]
+
+    @staticmethod
+    def from_ints(v):
+        return Geom(*v)
+
+    def param_names(self):
+        """The network's parameters in the order the custom ops take and return them."""
+        names = SAR_PARAM_NAMES if self.sar else PARAM_NAMES
+        return [k for k in names if self.view or not k.startswith(('rgb_net0', 'rgb_net1'))]
+
+
+class Packed(Geom):
+    """bf16 weight streams + fp32 constants of one network, valid until the next optimizer step."""
+
+    def __init__(self, model, need_bwd=True, params=None, geom=None):
+        """From a model, or from `params` (name -> tensor) and `geom`."""
+        if geom is None:
+            geom = Geom.of_model(model)
+        Geom.__init__(self, *geom.ints())
+        p = params if params is not None else {k: v.detach() for k, v in model.named_parameters()}
         dev = p['density_net0.0.weight'].device
-        self.sar = 'final_angle.0.weight' in p
-        # without view directions (model.py:78-92, 283-302) there is no colour layer: width and view size 0
-        self.view = 'rgb_net0.0.weight' in p
-        H, W = cfg.hidden, (cfg.num_samples if self.view else 0)
-        D = 6 * (cfg.max_deg - cfg.min_deg)
-        V = 3 + 6 * (cfg.viewdirs_max_deg - cfg.viewdirs_min_deg) if self.view else 0
-        self.dims = MlpDims(D, V, H, W, int(self.sar))
-        self.fmt = TFRAG_FORMATS[getattr(cfg, 'wgrad_operands', None) or DEFAULT_WGRAD_OPERANDS]
-        self.H, self.W, self.D, self.V = H, W, D, V
-        self.HT, self.WT = (H + 31) // 32, (W + 31) // 32
-        self.DKS, self.VKS = (D + 15) // 16, (V + 15) // 16
+        assert self.sar == ('final_angle.0.weight' in p) and self.view == ('rgb_net0.0.weight' in p)
+        H, W, D, V = self.H, self.W, self.D, self.V
         HP, WP = 32 * self.HT, 32 * self.WT
         nf, nb, nc = c_int64(), c_int64(), c_int64()
         check(lib().nerf_mlp_sizes(ctypes.byref(self.dims), ctypes.byref(nf), ctypes.byref(nb), ctypes.byref(nc)))
@@ -143,7 +174,11 @@ class Packed:
         self.fwd_flops = 2.0 * macs_fwd
         self.bwd_dx_flops = 2.0 * macs_dx
         self.wgrad_flops = 2.0 * macs_fwd
-        self.DT, self.VT = (self.DKS + 1) // 2, (self.VKS + 1) // 2
+        # what the chain kernels issue for the true layer sizes: rgb_net0 is folded into rgb_net1, one H x H product
+        # less per pass (transposition products and padding are overhead, not counted)
+        fold = H * H if self.view else 0
+        self.fwd_flops_exec = 2.0 * (macs_fwd - fold)
+        self.bwd_dx_flops_exec = 2.0 * (macs_dx - fold)
         # bf16 operand bytes per sample that the weight-gradient launches read (see _wgrad_plan)
         self.wgrad_bytes = sum(_wgrad_launch_bytes(self, dys, xs) for dys, xs, _ in _wgrad_plan(self))
 
@@ -160,8 +195,14 @@ def _wgrad_plan(pk):
     plan = [one(0, HP, H, 'density_net0.0', 'enc', DP, D)]
     plan += [one(l, HP, H, 'density_net0.%d' % i, ('x', l - 1), HP, H) for l, i in ((1, 2), (2, 4), (3, 6))]
     # density_net1.0 takes [X3 | encoding]
-    plan += [([(4, HP, H, 'density_net1.0')], [(('x', 3), HP, H), ('enc', DP, D)],
-              [[('density_net1.0', 0), ('density_net1.0', H)]])]
+    if pk.fmt and pk.HT + pk.DT > 10:
+        # (max_deg 16: eleven X tiles are more than a 4-wave workgroup of the 8/6-bit kernel holds accumulators for
+        # beside eight dY tiles; the two column blocks take a launch each, the second without the bias sums)
+        plan += [one(4, HP, H, 'density_net1.0', ('x', 3), HP, H),
+                 ([(4, HP, H, None)], [('enc', DP, D)], [[('density_net1.0', H)]])]
+    else:
+        plan += [([(4, HP, H, 'density_net1.0')], [(('x', 3), HP, H), ('enc', DP, D)],
+                  [[('density_net1.0', 0), ('density_net1.0', H)]])]
     plan += [one(l, HP, H, 'density_net1.%d' % i, ('x', l - 1), HP, H) for l, i in ((5, 2), (6, 4), (7, 6))]
     # the folded colour layer and the density head both read the trunk output X7: [dY9 | density tile] x [X7 | view]
     # in one launch.  dY9^T X7 lands in the scratch pair '_g98' (fold_gradients turns it into the gradients of
@@ -202,6 +243,22 @@ def packed_for(model, need_bwd=True):
         pk = Packed(model, need_bwd)
         pk.versions = versions
         model._packed = pk
+    return pk
+
+
+_PACKED_BY_PARAMS = {}
+
+
+def packed_for_params(weights, geom, need_bwd=True):
+    """The packed streams for a parameter list in `geom.param_names()` order (what the custom ops receive), cached on
+    the tensors' storage and version like `packed_for`; a handful of entries at most (one per live network)."""
+    key = tuple(geom.ints()) + tuple((w.data_ptr(), w._version) for w in weights)
+    pk = _PACKED_BY_PARAMS.get(key)
+    if pk is None or (need_bwd and pk.wbwd is None):
+        if len(_PACKED_BY_PARAMS) >= 8:
+            _PACKED_BY_PARAMS.clear()
+        pk = Packed(None, need_bwd, params={k: w.detach() for k, w in zip(geom.param_names(), weights)}, geom=geom)
+        _PACKED_BY_PARAMS[key] = pk
     return pk
 
 
@@ -279,7 +336,8 @@ def mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=False, acts=None
                 for b in act_block_bytes(pk)]        # (22, SAR only: the trunk output once more in frag order)
         arr = (c_void_p * len(acts))(*[a.data_ptr() if a is not None else None for a in acts])
     saved = sum(a.numel() for a in acts if a is not None) if acts is not None else 0   # bytes the launch writes for the backward pass
-    with profiling.timed('mlp_fwd_kernel', flops=pk.fwd_flops * n_samples, bytes_=float(saved)):
+    with profiling.timed('mlp_fwd_kernel', flops=pk.fwd_flops * n_samples, bytes_=float(saved),
+                         flops_exec=pk.fwd_flops_exec * n_samples):
         check(lib().nerf_mlp_fwd(ctypes.byref(pk.dims), _raw(pk.wfwd), ptr(pk.consts), _raw(enc), _raw(view) if pk.view else None,
                                  n_samples, ray_div, n_rays, arr, pk.fmt, ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
                                  ptr(ln_stats), stream()))
@@ -300,7 +358,9 @@ def mlp_backward(pk, acts, n_samples, g_density, g_rgb, raw_rgb, g_angle=None, r
     g_density, g_rgb = f32c(g_density).reshape(-1), f32c(g_rgb).reshape(-1, 3)
     if pk.sar:
         g_angle = f32c(g_angle).reshape(-1, 2)
-    with profiling.timed('mlp_bwd_kernel', flops=pk.bwd_dx_flops * (n_real or n_samples), bytes_=float(sum(d.numel() for d in dys if d is not None))):
+    with profiling.timed('mlp_bwd_kernel', flops=pk.bwd_dx_flops * (n_real or n_samples),
+                         bytes_=float(sum(d.numel() for d in dys if d is not None)),
+                         flops_exec=pk.bwd_dx_flops_exec * (n_real or n_samples)):
         check(lib().nerf_mlp_bwd(ctypes.byref(pk.dims), _raw(pk.wbwd), ptr(pk.consts), n_samples, ptr(g_density),
                                  ptr(g_rgb), ptr(g_angle), ptr(raw_density), ptr(raw_rgb), ptr(raw_angle),
                                  ptr(ln_stats), a_arr, d_arr, pk.fmt, stream()))
@@ -395,12 +455,13 @@ def _wgrad_launches(pk, acts, dys, n_samples, grads):
         d.tfrag_fmt = pk.fmt
         if ws is not None:
             d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-        flops = 0.0
+        flops = flops_exec = 0.0
         for i, (di, nf, nt, name) in enumerate(dsegs):
             d.dy[i], d.dy_feat[i], d.dy_true[i] = dys[di].data_ptr(), nf, nt
             if pk.fmt:
                 d.dy_scale[i] = dys[12 + di].data_ptr()
-            d.gb[i] = grads[name + '.bias'].data_ptr()
+            if name is not None:
+                d.gb[i] = grads[name + '.bias'].data_ptr()
         for j, (xs, kf, kt) in enumerate(xsegs):
             x = acts[20] if xs == 'enc' else acts[21] if xs == 'view' else acts[xs[1]]
             d.x[j], d.x_feat[j], d.x_true[j] = x.data_ptr(), kf, kt
@@ -410,13 +471,14 @@ def _wgrad_launches(pk, acts, dys, n_samples, grads):
                     w = grads[blk[0] + '.weight']
                     d.G[i][j], d.ld[i][j], d.col0[i][j] = w.data_ptr(), w.stride(0), blk[1]
                     flops += 2.0 * dsegs[i][2] * xsegs[j][2] * n_samples
+                    flops_exec += 2.0 * dsegs[i][2] * xsegs[j][2] * n_samples
                     if blk[0] == '_g98':        # this block stands for rgb_net0's weight gradient as well
                         flops += 2.0 * pk.H * pk.H * n_samples
         nf_all, kf_all = sum(s[1] for s in dsegs), sum(s[1] for s in xsegs)
         if pk.fmt:      # (the instantiation depends on the split into segments)
             nf_all, kf_all = tuple(s[1] for s in dsegs), tuple(s[1] for s in xsegs)
         # algorithmic work of the launch: every operand byte once, 2 FLOP per true multiply-add
-        with profiling.timed(wgrad_kernel_name(nf_all, kf_all, pk.fmt), flops=flops,
+        with profiling.timed(wgrad_kernel_name(nf_all, kf_all, pk.fmt), flops=flops, flops_exec=flops_exec,
                              bytes_=_wgrad_launch_bytes(pk, dsegs, xsegs) * n_samples):
             check(lib().nerf_mlp_wgrad_multi(ctypes.byref(d), n_samples, WGRAD_GRID, stream()))
 
@@ -512,7 +574,7 @@ def render_level(model, t_vals, rays, viewf, S, need_weights=True):
     comp, dist, acc = torch.empty(n, 3, device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev)
     weights = torch.empty(n, S, device=dev) if need_weights else None
     act = _lib.NerfActivation(1, float(model.rgb_padding), float(model.density_bias))
-    with profiling.timed('mlp_fwd_kernel', flops=pk.fwd_flops * n * S, bytes_=0.0):
+    with profiling.timed('mlp_fwd_kernel', flops=pk.fwd_flops * n * S, bytes_=0.0, flops_exec=pk.fwd_flops_exec * n * S):
         check(lib().nerf_mlp_fwd_composite(ctypes.byref(pk.dims), _raw(pk.wfwd), ptr(pk.consts), _raw(encf),
                                            _raw(viewf) if pk.view else None, n, S, ptr(f32c(t_vals)),
                                            ptr(f32c(rays.directions).reshape(n, 3)), int(bool(model.white_bkgd)),

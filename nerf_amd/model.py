@@ -182,6 +182,8 @@ class MipNeRF(_RenderModule):
         tensors (`t_rand [N,S0+1]`, `u_rand {level: [N,S_l+1]}`, `noise {level: [N,S_l,1]}`) replace
         the draws the reference makes internally, in the same places (model.py:100-151)."""
         cfg = self.config
+        if self._precision() == 'bf16' and (torch.compiler.is_compiling() or getattr(cfg, 'use_custom_ops', False)):
+            return self._forward_custom_ops(rays, t_rand, u_rand, noise)
         levels = self._level_samples()
         o, d = rays.origins, rays.directions
         n = o.shape[0]
@@ -232,6 +234,60 @@ class MipNeRF(_RenderModule):
             with torch.no_grad():
                 rgb = raw_rgb * (1 + 2 * self.rgb_padding) - self.rgb_padding
                 density = torch.nn.functional.softplus(raw_density + self.density_bias)
+                raws = torch.cat((rgb, density), -1).cpu()
+            return out + (raws,)
+        return out
+
+    def _forward_custom_ops(self, rays, t_rand=None, u_rand=None, noise=None):
+        """`forward` on the bf16 chain written with the `torch.ops.nerf_amd.*` custom ops only (nerf_amd.torch_ops):
+        every kernel is one opaque, differentiable node, so `torch.compile(fullgraph=True)`, `torch.export` and
+        `make_fx` trace the whole coarse + fine render (model.py:100-151) without a graph break.  Taken automatically
+        while a compiler traces, or with `config.use_custom_ops = True`; same kernels, same results as the eager
+        wrappers (which add the persistent weight cache and the in-place gradient accumulation of the train loop)."""
+        from . import mlp_bf16, torch_ops
+        K = torch.ops.nerf_amd
+        cfg = self.config
+        levels = self._level_samples()
+        o, d = rays.origins, rays.directions
+        n = o.shape[0]
+        geom = mlp_bf16.Geom.of_model(self)
+        params = dict(self.named_parameters())
+        weights = [params[k] for k in geom.param_names()]
+        shape = mlp_bf16.RAY_SHAPES[self.ray_shape]
+        radii = rays.radii.reshape(n)
+        view = K.view_frag(rays.viewdirs, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg) if self.use_viewdirs else None
+        save = torch.is_grad_enabled()
+        eps = float(torch.finfo(torch.float32).eps)
+        comp_rgbs, distances, accs = [], [], []
+        t_vals = weights_l = raw_rgb = raw_density = None
+        for l, S in enumerate(levels):
+            if l == 0:
+                tr = None
+                if self.randomized:
+                    tr = t_rand if t_rand is not None else torch.rand(n, S + 1, device=o.device)
+                t_vals = K.stratified_t(rays.near, rays.far, S, tr, False)
+            else:
+                ur = None
+                if self.randomized:
+                    ur = u_rand[l] if u_rand is not None else torch.rand(n, S + 1, device=o.device) * (1 / (S + 1) - eps)
+                t_vals = K.resample(t_vals, weights_l.detach(), S + 1, float(self.resample_padding), ur, True)
+            enc = K.encode_frag(t_vals, o, d, radii, shape, cfg.min_deg, cfg.max_deg)
+            raw_density, raw_rgb, _, _, _ = K.mlp_fwd(weights, enc, view, geom.ints(), n * S, S, n, save)
+            raw_density = raw_density.reshape(n, S)
+            raw_rgb = raw_rgb.reshape(n, S, 3)
+            if self.randomized and self.density_noise:
+                nz = noise[l].reshape(n, S) if noise is not None else torch.rand(n, S, device=o.device)
+                raw_density = raw_density + self.density_noise * nz
+            comp_rgb, distance, acc, weights_l = K.composite(raw_rgb, raw_density, t_vals, d, bool(self.white_bkgd), True,
+                                                             float(self.rgb_padding), float(self.density_bias))
+            comp_rgbs.append(comp_rgb)
+            distances.append(distance)
+            accs.append(acc)
+        out = (torch.stack(comp_rgbs), torch.stack(distances), torch.stack(accs))
+        if self.return_raw:
+            with torch.no_grad():
+                rgb = raw_rgb * (1 + 2 * self.rgb_padding) - self.rgb_padding
+                density = torch.nn.functional.softplus(raw_density[..., None] + self.density_bias)
                 raws = torch.cat((rgb, density), -1).cpu()
             return out + (raws,)
         return out

@@ -25,13 +25,22 @@ from ._lib import NerfActivation, check, lib, ptr, stream
 _EPS32 = float(torch.finfo(torch.float32).eps)
 
 
+def _grads_ready(model):
+    """Every trainable tensor of the network takes part and owns a contiguous fp32 `.grad` to add into (a frozen
+    parameter, or one without a gradient buffer, sends the step through autograd instead)."""
+    for k, p in model.named_parameters():
+        if k.endswith('scales'):
+            continue
+        if not p.requires_grad or p.grad is None or p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+            return False
+    return True
+
+
 def supported(model):
-    """The fused step covers the bf16 network without density noise (model.py:135-136 draws noise between the MLP
-    and the compositing; that variant goes through autograd)."""
+    """The fused step covers the bf16 network with every parameter trainable; `return_raw` goes through autograd."""
     cfg = model.config
-    return (getattr(cfg, 'mlp_precision', 'fp32') == 'bf16'
-            and not (model.randomized and model.density_noise) and not getattr(model, 'return_raw', False)
-            and hasattr(model, 'white_bkgd'))
+    return (getattr(cfg, 'mlp_precision', 'fp32') == 'bf16' and not getattr(model, 'return_raw', False)
+            and hasattr(model, 'white_bkgd') and _grads_ready(model))
 
 
 class NerfStepper:
@@ -79,9 +88,10 @@ class NerfStepper:
         lo = 64 * self.blk0[l]
         return t[lo:lo + self.n * S]
 
-    def step(self, rays, pixels, global_mask_sum=None, t_rand=None, u_rand=None):
+    def step(self, rays, pixels, global_mask_sum=None, t_rand=None, u_rand=None, noise=None):
         """Forward + loss + backward of one batch; the weight gradients are ADDED into the parameters' `.grad`
-        (views of the caller's gradient bucket).  -> loss (device scalar), comp_rgb [L,N,3] (this step's buffers)."""
+        (views of the caller's gradient bucket).  -> loss (device scalar), comp_rgb [L,N,3] (this step's buffers).
+        `t_rand`, `u_rand`, `noise` as in MipNeRF.forward: pre-drawn random tensors in place of the device draws."""
         model, n, dev = self.model, self.n, self.dev
         cfg = model.config
         assert rays.origins.shape[0] == n
@@ -121,6 +131,12 @@ class NerfStepper:
             raw_d, raw_c = self._samples(self.raw_density, l), self._samples(self.raw_rgb, l)
             mlp_bf16.mlp_forward(pk, self.enc[l], self.view, n * S, S, n, acts=self._level(self.acts, self.act_bytes, l),
                                  raw=(raw_d, raw_c))
+            if model.randomized and model.density_noise:                        # model.py:135-136
+                # U(0,1) noise on the raw density between the MLP and the compositing; it shifts the point at which the
+                # density activation is evaluated and leaves d(noisy) / d(raw) = 1, so the buffer is perturbed in place
+                # (the NeRF backward chain does not read the raw density again)
+                nz = f(noise[l], n * S) if noise is not None else torch.rand(n * S, device=dev)
+                raw_d.add_(nz * float(model.density_noise))      # (product rounded, then the sum: as the reference's +=)
             check(L_.nerf_composite_train(ptr(raw_c), ptr(raw_d), ptr(t), ptr(d), ptr(target), ptr(lossmult),
                                           ptr(self.inv_mask_sum), 1.0 if l == nl - 1 else cwd, n, S,
                                           int(bool(model.white_bkgd)), act, ptr(self.comp[l]), ptr(self.dist[l]),
@@ -136,10 +152,10 @@ class NerfStepper:
 
 
 def sar_supported(model):
-    """The fused SAR step covers the bf16 network without density noise (model.py:362-363)."""
+    """The fused SAR step covers the bf16 network with every parameter trainable."""
     cfg = model.config
-    return (getattr(cfg, 'mlp_precision', 'fp32') == 'bf16' and not (model.randomized and model.density_noise)
-            and not getattr(model, 'return_raw', False) and hasattr(model, 'rays_per_chunk'))
+    return (getattr(cfg, 'mlp_precision', 'fp32') == 'bf16' and not getattr(model, 'return_raw', False)
+            and hasattr(model, 'rays_per_chunk') and _grads_ready(model))
 
 
 class SarStepper:
@@ -149,14 +165,23 @@ class SarStepper:
     slice of every saved buffer (whole 256-sample tiles).  The matched filter and the loss (model.py:377-380,
     util_modules.py:74-89) go through torch's autograd with the accumulated range profiles as leaves; their gradient
     is scattered back per pass (`nerf_scatter_bwd`), and then ONE backward chain and ONE weight-gradient launch per
-    layer cover the samples of all passes, adding into the parameters' `.grad`."""
+    layer cover the samples of all passes, adding into the parameters' `.grad`.
 
-    def __init__(self, model):
+    With `world_size > 1` the ray chunks are dealt round-robin to the ranks as `SARNeRF.forward` deals them (the
+    reference adds the chunks' profiles, model.py:371, so whole chunks shard without changing the result): this
+    rank renders chunks `rank, rank + world_size, ...`, the per-level profiles are SUM-all-reduced ahead of the
+    matched filter, every rank evaluates the same loss and back-propagates it into its own chunks; the caller
+    SUM-all-reduces the weight gradients."""
+
+    def __init__(self, model, rank=0, world_size=1):
         self.model = model
         self.dev = dev = model.device
+        self.rank, self.world = int(rank), int(world_size)
         pk = mlp_bf16.packed_for(model, need_bwd=True)
         self.R, self.S, self.L = model.rays_per_chunk, model.num_samples, model.num_levels
-        self.passes = model.num_ray_iters * self.L
+        self.chunks = model.num_ray_iters
+        self.own = [c for c in range(self.chunks) if c % self.world == self.rank]
+        self.passes = len(self.own) * self.L
         nb = mlp_bf16.n_blocks(self.R * self.S)
         self.nblk, self.nblk_total = nb, nb * self.passes
         u8 = lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -200,11 +225,13 @@ class SarStepper:
                 az, el = az_el[c]
             else:                                                                              # model.py:319-320
                 az, el = torch.randn(R) * SAR_AZ_SIGMA, torch.randn(R) * SAR_EL_SIGMA
+            if c % self.world != self.rank:     # another rank's chunk (its beam offsets were drawn above, so that every
+                continue                        # rank walks the same host generator sequence)
             ray_d, ray_p = ops.sar_raygen(az.to(dev), el.to(dev))
             viewf = mlp_bf16.view_frag(ray_d, cfg.viewdirs_min_deg, cfg.viewdirs_max_deg) if pk.view else None
             t_vals = weights = None
             for l in range(L):
-                q = c * L + l
+                q = (c // self.world) * L + l
                 if l == 0:
                     tr = None
                     if model.randomized:
@@ -220,20 +247,29 @@ class SarStepper:
                 lo = 64 * q * self.nblk
                 raw = tuple(t[lo:lo + M] for t in (self.raw_density, self.raw_rgb, self.raw_angle, self.ln_stats))
                 mlp_bf16.mlp_forward(pk, encf, viewf, M, R, R, save=True, acts=self._slice(self.acts, self.act_bytes, q), raw=raw)
+                dens = raw[0]
+                if model.randomized and model.density_noise:                                   # model.py:362-363
+                    # the compositing sees the perturbed density; the LayerNorm backward needs the network's own output,
+                    # so the perturbed copy is a separate tensor (kept for nerf_scatter_bwd)
+                    dens = torch.rand(M, device=dev).mul_(float(model.density_noise)).add_(raw[0])
                 pulse, dist, acc = torch.empty(nsam, 2, device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev)
                 weights, alpha = torch.empty(R, S, device=dev), torch.empty(R, S, device=dev)
                 ray_ret, ray_bin, comp5 = torch.empty(R, 2, device=dev), i32(R), torch.empty(R, 5, device=dev)
                 winner, status = i32(nsam), i32(1)
-                check(L_.nerf_scatter_fwd(ptr(raw[1]), ptr(raw[2]), ptr(raw[0]), ptr(ray_p), ptr(t_vals), ptr(ray_d),
+                check(L_.nerf_scatter_fwd(ptr(raw[1]), ptr(raw[2]), ptr(dens), ptr(ray_p), ptr(t_vals), ptr(ray_d),
                                           ptr(pulse_bins), R, S, nsam, wl, act, ptr(pulse), ptr(dist), ptr(acc),
                                           ptr(weights), ptr(alpha), ptr(ray_ret), ptr(ray_bin, torch.int32), ptr(comp5),
                                           ptr(winner, torch.int32), ptr(status, torch.int32), st))
                 comp[l] += pulse
-                saved.append((ray_p, t_vals, ray_d, ray_bin, comp5, dist))
+                saved.append((ray_p, t_vals, ray_d, ray_bin, comp5, dist, dens if dens is not raw[0] else None))
                 statuses.append(status)
-        if getattr(cfg, 'check_range', True) and int(torch.cat(statuses).min()) != 0:
+        if statuses and getattr(cfg, 'check_range', True) and int(torch.cat(statuses).min()) != 0:
             raise IndexError('range bin index out of bounds: a ray distance lies beyond the last pulse bin '
                              '(far > near + (nsam - 1) * mpp)')
+        if self.world > 1:                      # the one exchange step of the pulse: nsam x 2 floats per level
+            from .train import _all_reduce_sum
+            for x in comp:
+                _all_reduce_sum(x)
         # matched filter, per-pulse normalisation and loss through autograd, with the range profiles as leaves
         leaves = [x.requires_grad_(True) for x in comp]
         mf = mfilt.to(dev)
@@ -244,14 +280,17 @@ class SarStepper:
             outs.append(torch.view_as_real(zc / torch.std(zc, dim=-1)[..., None]))
         loss, _ = model.loss_function.level_losses(torch.stack(outs), target.to(dev))
         g_comp = torch.autograd.grad(loss, leaves)
-        for q, (ray_p, t_vals, ray_d, ray_bin, comp5, dist) in enumerate(saved):
+        for q, (ray_p, t_vals, ray_d, ray_bin, comp5, dist, dens) in enumerate(saved):
             lo = 64 * q * self.nblk
             sl = lambda t: t[lo:lo + M]
-            check(L_.nerf_scatter_bwd(ptr(sl(self.raw_rgb)), ptr(sl(self.raw_angle)), ptr(sl(self.raw_density)), ptr(ray_p),
+            check(L_.nerf_scatter_bwd(ptr(sl(self.raw_rgb)), ptr(sl(self.raw_angle)),
+                                      ptr(dens if dens is not None else sl(self.raw_density)), ptr(ray_p),
                                       ptr(t_vals), ptr(ray_d), ptr(g_comp[q % L].contiguous()), ptr(ray_bin, torch.int32),
                                       ptr(comp5), ptr(dist), None, None, R, S, nsam, wl, act, ptr(sl(self.g_rgb)),
                                       ptr(sl(self.g_angle)), ptr(sl(self.g_density)), st))
         m_all = 64 * self.nblk_total
+        if m_all == 0:                          # a rank that was dealt no chunk has nothing to differentiate
+            return loss.detach()
         mlp_bf16.mlp_backward(pk, self.acts, m_all, self.g_density, self.g_rgb, self.raw_rgb, self.g_angle, self.raw_density,
                               self.raw_angle, self.ln_stats, dys=self.dys, n_real=M * self.passes)
         P = {k: v.detach() for k, v in model.named_parameters()}
@@ -266,12 +305,12 @@ class SarStepper:
         return loss.detach()
 
 
-def sar_stepper_for(model):
+def sar_stepper_for(model, rank=0, world_size=1):
     s = getattr(model, '_sar_stepper', None)
     if (s is None or s.dev != model.device or (s.R, s.S, s.L) != (model.rays_per_chunk, model.num_samples, model.num_levels)
-            or s.passes != model.num_ray_iters * model.num_levels):
-        model._sar_stepper = None
-        s = SarStepper(model)
+            or s.chunks != model.num_ray_iters or (s.rank, s.world) != (rank, world_size)):
+        model._sar_stepper = s = None   # release the old buffers before the new ones are allocated
+        s = SarStepper(model, rank, world_size)
         model._sar_stepper = s
     return s
 
@@ -279,7 +318,7 @@ def sar_stepper_for(model):
 def stepper_for(model, n_rays):
     s = getattr(model, '_stepper', None)
     if s is None or s.n != n_rays or s.levels != model._level_samples() or s.dev != model.device:
-        model._stepper = None           # release the old buffers before the new ones are allocated
+        model._stepper = s = None       # release the old buffers (no name may still hold them) before the new ones are allocated
         s = NerfStepper(model, n_rays)
         model._stepper = s
     return s

@@ -12,8 +12,14 @@ capture works unchanged.  All take contiguous fp32 tensors on one HIP device, fl
     torch.ops.nerf_amd.composite_bwd(...)                                                its hand-written backward
     torch.ops.nerf_amd.scatter(rgb, angle, density, power, t_vals, dirs, pulse_bins, ...) utils.py:321-380 (differentiable)
     torch.ops.nerf_amd.scatter_bwd(...)                                                  its hand-written backward
+    torch.ops.nerf_amd.encode_frag(t_vals, origins, directions, radii, ray_shape, lo, hi) cast + IPE as operand fragments
+    torch.ops.nerf_amd.view_frag(dirs, lo, hi)                                            util_modules.py:49, model.py:125-126
+    torch.ops.nerf_amd.mlp_fwd(weights, enc, view, geom, M, ray_div, n_rays, save)        model.py:117-132, 343-359 (differentiable
+                                                                                          w.r.t. the weights)
+    torch.ops.nerf_amd.mlp_bwd(weights, geom, M, g_density, g_rgb, g_angle, outs, acts)   the input-gradient chain
+    torch.ops.nerf_amd.mlp_wgrad(weights, geom, M, acts, dys)                             the weight gradients
 """
-from typing import Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor
@@ -102,6 +108,7 @@ def _composite_setup(ctx, inputs, output):
     rgb, density, t_vals, dirs, white_bkgd, apply_act, rgb_padding, density_bias = inputs
     ctx.save_for_backward(rgb, density, t_vals, dirs)
     ctx.meta = (white_bkgd, apply_act, rgb_padding, density_bias)
+    ctx.mark_non_differentiable(output[3])      # weights: consumed under no_grad upstream; no gradient is implemented
 
 
 def _composite_backward(ctx, g_comp, g_dist, g_acc, _g_w):
@@ -203,3 +210,137 @@ def _scatter_backward(ctx, g_pulse, g_dist, g_acc, *_):
 
 
 scatter.register_autograd(_scatter_backward, setup_context=_scatter_setup)
+
+
+# ---- the fused bf16 MLP (csrc/mlp_bf16.hip) -------------------------------------------------------------------------
+# `weights`: the network's parameters in `Geom.param_names()` order (the reference's nn.Linear / LayerNorm tensors,
+# model.py:54-93, 258-302); `geom` = [enc_dim, view_dim, hidden, width, sar, operand format] (`Geom.ints()`).
+# Buffers that a geometry does not use (None in the eager wrappers) are zero-length tensors here.
+
+def _geom(geom):
+    from . import mlp_bf16
+    return mlp_bf16.Geom.from_ints(list(geom))
+
+
+def _byte_buffers(sizes, nblk, like):
+    return [like.new_empty(nblk * b if b is not None else 0, dtype=torch.uint8) for b in sizes]
+
+
+def _opt(buffers):
+    return [b if b.numel() > 0 else None for b in buffers]
+
+
+@torch.library.custom_op('nerf_amd::encode_frag', mutates_args=())
+def encode_frag(t_vals: Tensor, origins: Tensor, directions: Tensor, radii: Tensor, ray_shape: int, min_deg: int,
+                max_deg: int) -> Tensor:
+    """Fenceposts -> Gaussians -> integrated positional encoding as bf16 operand fragments (a byte buffer)."""
+    from . import mlp_bf16
+    return mlp_bf16.encode_frag(t_vals, origins, directions, radii, _RAY_SHAPES[ray_shape], min_deg, max_deg)
+
+
+@encode_frag.register_fake
+def _(t_vals, origins, directions, radii, ray_shape, min_deg, max_deg):
+    n, s1 = t_vals.shape
+    nblk = ((n * (s1 - 1) + 255) // 256) * 4
+    return t_vals.new_empty(nblk * ((6 * (max_deg - min_deg) + 15) // 16) * 2 * 1024, dtype=torch.uint8)
+
+
+@torch.library.custom_op('nerf_amd::view_frag', mutates_args=())
+def view_frag(dirs: Tensor, min_deg: int, max_deg: int) -> Tensor:
+    from . import mlp_bf16
+    return mlp_bf16.view_frag(dirs, min_deg, max_deg)
+
+
+@view_frag.register_fake
+def _(dirs, min_deg, max_deg):
+    return dirs.new_empty(dirs.shape[0] * ((6 * (max_deg - min_deg) + 3 + 15) // 16) * 2 * 16, dtype=torch.uint8)
+
+
+@torch.library.custom_op('nerf_amd::mlp_fwd', mutates_args=())
+def mlp_fwd(weights: Sequence[Tensor], enc: Tensor, view: Optional[Tensor], geom: Sequence[int], n_samples: int,
+            ray_div: int, n_rays: int, save: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, List[Tensor]]:
+    """-> raw_density [M,1], raw_rgb [M,3] (after the sigmoid), raw_angle [M,2] and LayerNorm statistics [M,2] (SAR; else
+    empty), and the buffers the backward pass reads (empty list when `save` is false)."""
+    from . import mlp_bf16
+    g = _geom(geom)
+    pk = mlp_bf16.packed_for_params(list(weights), g, need_bwd=save)
+    d, rgb, ang, acts, ln = mlp_bf16.mlp_forward(pk, enc, view, n_samples, ray_div, n_rays, save=save)
+    e = lambda x, *shape: x if x is not None else enc.new_empty(*shape, dtype=torch.float32)
+    acts = [a if a is not None else enc.new_empty(0) for a in acts] if acts is not None else []
+    return d.reshape(-1, 1), rgb, e(ang, 0, 2), e(ln, 0, 2), acts
+
+
+@mlp_fwd.register_fake
+def _(weights, enc, view, geom, n_samples, ray_div, n_rays, save):
+    from . import mlp_bf16
+    g = _geom(geom)
+    f = lambda *shape: enc.new_empty(*shape, dtype=torch.float32)
+    acts = _byte_buffers(mlp_bf16.act_block_bytes(g), mlp_bf16.n_blocks(n_samples), enc) if save else []
+    return (f(n_samples, 1), f(n_samples, 3), f(n_samples if g.sar else 0, 2), f(n_samples if (g.sar and save) else 0, 2),
+            acts)
+
+
+@torch.library.custom_op('nerf_amd::mlp_bwd', mutates_args=())
+def mlp_bwd(weights: Sequence[Tensor], geom: Sequence[int], n_samples: int, g_density: Tensor, g_rgb: Tensor,
+            g_angle: Tensor, raw_density: Tensor, raw_rgb: Tensor, raw_angle: Tensor, ln_stats: Tensor,
+            acts: Sequence[Tensor]) -> List[Tensor]:
+    """The input-gradient chain: dL/d(raw outputs) -> dL/d(every layer's pre-activation) as transposed fragments."""
+    from . import mlp_bf16
+    g = _geom(geom)
+    pk = mlp_bf16.packed_for_params(list(weights), g, need_bwd=True)
+    sar = (g_angle, raw_density.reshape(-1), raw_angle, ln_stats) if g.sar else (None, None, None, None)
+    dys = mlp_bf16.mlp_backward(pk, _opt(acts), n_samples, g_density.reshape(-1), g_rgb, raw_rgb, *sar)
+    return [x if x is not None else g_rgb.new_empty(0, dtype=torch.uint8) for x in dys]
+
+
+@mlp_bwd.register_fake
+def _(weights, geom, n_samples, g_density, g_rgb, g_angle, raw_density, raw_rgb, raw_angle, ln_stats, acts):
+    from . import mlp_bf16
+    return _byte_buffers(mlp_bf16.dy_block_bytes(_geom(geom)), mlp_bf16.n_blocks(n_samples), acts[0])
+
+
+@torch.library.custom_op('nerf_amd::mlp_wgrad', mutates_args=())
+def mlp_wgrad(weights: Sequence[Tensor], geom: Sequence[int], n_samples: int, acts: Sequence[Tensor],
+              dys: Sequence[Tensor]) -> List[Tensor]:
+    """The weight-gradient pass: one gradient per entry of `weights`, in the same order."""
+    from . import mlp_bf16
+    g = _geom(geom)
+    names = g.param_names()
+    pk = mlp_bf16.packed_for_params(list(weights), g, need_bwd=True)
+    grads = {k: torch.zeros_like(w, dtype=torch.float32) for k, w in zip(names, weights)}
+    if g.sar:
+        dev = weights[0].device
+        grads['_dens.weight'], grads['_dens.bias'] = torch.zeros(3, g.H, device=dev), torch.zeros(3, device=dev)
+        grads['_heads.weight'] = torch.zeros(5, g.W if g.view else g.H, device=dev)
+        grads['_heads.bias'] = torch.zeros(5, device=dev)
+    mlp_bf16.mlp_weight_grads(pk, _opt(acts), _opt(dys), n_samples, grads)
+    if g.sar:
+        grads.update(mlp_bf16.sar_head_gradients({k: w.detach() for k, w in zip(names, weights)}, grads))
+    return [grads[k] for k in names]
+
+
+@mlp_wgrad.register_fake
+def _(weights, geom, n_samples, acts, dys):
+    return [torch.empty_like(w, dtype=torch.float32) for w in weights]
+
+
+def _mlp_setup(ctx, inputs, output):
+    weights, enc, view, geom, n_samples, ray_div, n_rays, save = inputs
+    d, rgb, ang, ln, acts = output
+    ctx.geom, ctx.n_samples, ctx.n_weights, ctx.saved_acts = list(geom), n_samples, len(weights), save
+    ctx.save_for_backward(*weights, d, rgb, ang, ln, *acts)
+    ctx.mark_non_differentiable(ln, *acts)
+
+
+def _mlp_backward(ctx, g_density, g_rgb, g_angle, _g_ln, _g_acts):
+    if not ctx.saved_acts:
+        raise RuntimeError('nerf_amd::mlp_fwd was called with save=False: nothing was kept for a backward pass')
+    nw = ctx.n_weights
+    weights, (d, rgb, ang, ln), acts = ctx.saved_tensors[:nw], ctx.saved_tensors[nw:nw + 4], ctx.saved_tensors[nw + 4:]
+    z = lambda g, like: g.contiguous() if g is not None else torch.zeros_like(like)
+    dys = mlp_bwd(weights, ctx.geom, ctx.n_samples, z(g_density, d), z(g_rgb, rgb), z(g_angle, ang), d, rgb, ang, ln, acts)
+    grads = mlp_wgrad(weights, ctx.geom, ctx.n_samples, acts, dys)
+    return grads, None, None, None, None, None, None, None
+
+
+mlp_fwd.register_autograd(_mlp_backward, setup_context=_mlp_setup)

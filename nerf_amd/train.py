@@ -191,11 +191,13 @@ def sar_train_step(model, batch, optimizer, rank=0, world_size=1, scheduler=None
     bucket = grad_bucket(model)
     bucket.zero()
     from . import stepper
-    if fused and world_size == 1 and stepper.sar_supported(model):
+    if fused and stepper.sar_supported(model):
         # the pulse as a fixed launch sequence: one backward chain and one weight-gradient pass for all passes
-        loss = stepper.sar_stepper_for(model).step(ray_o, mfilt, radii, near, far, pulse_data.shape[1], mpp, pulse_data,
-                                                   **draws)
+        # (several ranks: each over its own chunks, the range profiles all-reduced inside the step)
+        loss = stepper.sar_stepper_for(model, rank, world_size).step(ray_o, mfilt, radii, near, far, pulse_data.shape[1],
+                                                                     mpp, pulse_data, **draws)
         bucket.attach()
+        bucket.all_reduce(world_size)
         optimizer.step()
         if scheduler is not None:
             scheduler.step()
@@ -222,7 +224,11 @@ class GraphedSarStep:
     about a hundred short launches -- samplers, encoders, chain kernels, scatter, FFTs, loss, the backward of all of
     them, AdamW, weight repack -- and a step issued launch by launch is bound by the host; replaying the captured
     graph leaves only the kernels.  Needs one rank, `config.check_range = False` (the range check reads a status
-    word back, which a capture cannot do) and an optimizer built with `capturable=True`.  The beam offsets are
+    word back, which a capture cannot do) and an optimizer built with `capturable=True`.  The learning rate must be
+    a device tensor for a replay to see a new value (a Python number is baked into the captured kernels' arguments):
+    a float `lr` of a parameter group is replaced by a one-element device tensor here, before the warm-up steps, and
+    `step(lr=...)` / `set_lr` write into it (the reference steps MipLRDecay after every optimizer step,
+    model.py:389-393).  The beam offsets are
     drawn on the device (the reference draws them on the host, model.py:319-320: same distribution, another
     stream of numbers); every replay draws afresh.  The `warmup` eager runs that precede the capture are real
     optimizer steps."""
@@ -234,6 +240,11 @@ class GraphedSarStep:
             raise ValueError('GraphedSarStep: build the optimizer with capturable=True')
         self.model, self.optimizer = model, optimizer
         dev = model.device
+        for g in optimizer.param_groups:        # see the class comment: only a tensor lr reaches a replay
+            if not torch.is_tensor(g['lr']):
+                g['lr'] = torch.tensor(float(g['lr']), dtype=torch.float32, device=dev)
+            elif g['lr'].device != dev:
+                raise ValueError('GraphedSarStep: the optimizer\'s tensor lr must live on the model\'s device')
         self.batch = tuple(x.to(dev).clone() if torch.is_tensor(x) else x for x in batch)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -252,16 +263,34 @@ class GraphedSarStep:
                   torch.randn(m.rays_per_chunk, device=m.device) * SAR_EL_SIGMA) for _ in range(m.num_ray_iters)]
         return sar_train_step(m, self.batch, self.optimizer, az_el=az_el)
 
-    def step(self, batch=None, lr=None):
+    def set_lr(self, lr):
+        """Write `lr` (a number, or one per parameter group) into the optimizer's tensor learning rates."""
+        groups = self.optimizer.param_groups
+        lrs = list(lr) if isinstance(lr, (list, tuple)) else [lr] * len(groups)
+        for g, v in zip(groups, lrs):
+            if not torch.is_tensor(g['lr']):
+                raise RuntimeError('GraphedSarStep: a parameter group\'s lr was replaced by a Python number after the '
+                                   'capture; a replay would not see it')
+            g['lr'].fill_(float(v))
+
+    def step(self, batch=None, lr=None, scheduler=None):
         """Replay on `batch` (copied into the captured tensors; None = the same pulse again) -> the loss tensor of
-        the capture (overwritten by every replay).  `lr` updates a tensor learning rate in place."""
+        the capture (overwritten by every replay).  `lr` is written into the tensor learning rates ahead of the
+        replay; `scheduler` (e.g. MipLRDecay on this optimizer) is stepped after it, and the rate it computes is
+        written back into the tensors (schedulers assign Python numbers to `param_groups[i]['lr']`)."""
         if batch is not None:
             for dst, src in zip(self.batch, batch):
                 if torch.is_tensor(dst):
                     dst.copy_(src)
         if lr is not None:
-            for g in self.optimizer.param_groups:
-                g['lr'].fill_(lr) if torch.is_tensor(g['lr']) else g.__setitem__('lr', lr)
+            self.set_lr(lr)
         self.graph.replay()
+        if scheduler is not None:
+            tensors = [g['lr'] for g in self.optimizer.param_groups]
+            scheduler.step()
+            for g, t in zip(self.optimizer.param_groups, tensors):
+                if g['lr'] is not t:            # the scheduler put a number there: keep the tensor, take its value
+                    t.fill_(float(g['lr']))
+                    g['lr'] = t
         self.model._weights_changed()           # the packed streams outside the graph are one step behind
         return self.loss

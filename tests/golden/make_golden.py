@@ -261,14 +261,20 @@ def _draws_nerf(n, level_samples, seed, randomized):
 
 
 def gen_nerf_e2e(only=None):
-    for tag, cfgkw, levels, n, wseed in (
+    # (tag, config, samples per level, rays, weight seed, ray seed, draw seed)
+    for tag, cfgkw, levels, n, wseed, rseed, dseed in (
             ('small_noview', dict(hidden=64, num_samples=16, max_deg=4, use_viewdirs=False, ray_shape='cylinder'),
-             [16, 16], 48, 14),
-            ('small', dict(hidden=64, num_samples=16, max_deg=4), [16, 16], 48, 11),
-            ('small_det', dict(hidden=64, num_samples=16, max_deg=4, randomized=False, white_bkgd=True), [16, 16], 48, 11),
-            ('c1', dict(), [64, 64], 64, 12),
-            ('c3', dict(num_samples=128), [64, 128], 64, 13),
-            ('c3_1k', dict(num_samples=128), [64, 128], 1024, 13)):
+             [16, 16], 48, 14, 20, 77),
+            ('small', dict(hidden=64, num_samples=16, max_deg=4), [16, 16], 48, 11, 20, 77),
+            ('small_det', dict(hidden=64, num_samples=16, max_deg=4, randomized=False, white_bkgd=True), [16, 16], 48, 11,
+             20, 77),
+            ('c1', dict(), [64, 64], 64, 12, 20, 77),
+            ('c3', dict(num_samples=128), [64, 128], 64, 13, 20, 77),
+            ('c3_1k', dict(num_samples=128), [64, 128], 1024, 13, 20, 77),
+            # a second 1024-ray batch of the same configuration: other weights, rays, targets and draws
+            ('c3_1k_b', dict(num_samples=128), [64, 128], 1024, 29, 41, 83),
+            # the reference's own NeRF configuration (params.yaml:15-25): 128 + 128 samples, max_deg 16
+            ('yaml_1k', dict(num_samples=128, max_deg=16), [128, 128], 1024, 17, 43, 89)):
         if only is not None and tag not in only:
             continue
         cfg = nerf_cfg(**cfgkw)
@@ -279,14 +285,14 @@ def gen_nerf_e2e(only=None):
             assert sd[k].shape == p[k].shape, (k, sd[k].shape, p[k].shape)
         m.load_state_dict({**sd, **p})
         m.train()
-        rays = make_rays(n, 20, normalize=False)
-        g = torch.Generator().manual_seed(21)
+        rays = make_rays(n, rseed, normalize=False)
+        g = torch.Generator().manual_seed(rseed + 1)
         target = torch.rand(n, 3, generator=g)
-        rgb, dist, acc, inter = _compose_nerf(m, rays, cfg, levels, seed=77)
+        rgb, dist, acc, inter = _compose_nerf(m, rays, cfg, levels, seed=dseed)
         loss, psnr = m.loss_function(rgb, target, rays['lossmult'])
         names = [k for k, v in m.named_parameters() if v.requires_grad]
         grads = torch.autograd.grad(loss, [dict(m.named_parameters())[k] for k in names])
-        t_rand, u = _draws_nerf(n, levels, 77, cfg.randomized)
+        t_rand, u = _draws_nerf(n, levels, dseed, cfg.randomized)
         out = dict(rgb=rgb, dist=dist, acc=acc, loss=loss, psnr=psnr, target=target, levels=np.array(levels),
                    wseed=wseed, cfg=np.array(repr(vars(cfg))))
         for k, v in rays.items():
@@ -502,6 +508,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if _ARGS == ['c3_1k']:
         gen_nerf_e2e(only=('c3_1k',))
+        sys.exit(0)
+    if _ARGS and _ARGS[0] == 'nerf':          # nerf <tag> ...: only these end-to-end fixtures
+        gen_nerf_e2e(only=tuple(_ARGS[1:]))
         sys.exit(0)
     if _ARGS == ['ndc']:
         gen_ndc()

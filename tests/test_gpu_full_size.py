@@ -130,6 +130,64 @@ def test_training_fits_a_scene_from_device_generated_batches():
     assert after > before + 4.0, (before, after)
 
 
+def _fit_scene(precision, operands, steps, seed=3):
+    """`steps` training steps on the synthetic three-camera scene of the test above -> (fine-level PSNR over every
+    pixel of the three images with the sampling jitter off, mean training loss of the last 20 steps)."""
+    from nerf_amd.model import MipNeRF
+    from nerf_amd.rays import RayBatches
+    from nerf_amd.train import nerf_train_step
+    from nerf_amd.util_modules import MipLRDecay, mse_to_psnr
+    torch.manual_seed(seed)
+    c = cfg(True)
+    c.mlp_precision, c.wgrad_operands = precision, operands
+    c.lr_init, c.lr_final, c.max_steps, c.lr_delay_steps, c.lr_delay_mult = 2e-3, 2e-4, steps, 10, 0.1
+    m = MipNeRF(c).cuda().train()
+    opt = torch.optim.AdamW(m.parameters(), lr=c.lr_init, weight_decay=c.weight_decay, fused=True)
+    sched = MipLRDecay(opt, c.lr_init, c.lr_final, c.max_steps, c.lr_delay_steps, c.lr_delay_mult)
+    C, h, w = 3, 64, 64
+    c2w = torch.eye(4)[None, :3].repeat(C, 1, 1)
+    c2w[:, 2, 3] = 4.0
+    c2w[1, 0, 3], c2w[2, 1, 3] = 0.3, -0.3
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing='ij')
+    img = torch.stack([xx, yy, 0.5 + 0.5 * torch.sin(6.28 * (xx + yy))], -1)
+    images = img[None].repeat(C, 1, 1, 1).cuda()
+    batches = RayBatches(c2w.cuda(), h, w, 70.0, 2.0, 6.0, images=images, batch_size=4096, seed=1)
+    torch.manual_seed(100 + seed)                      # the sampling jitter: the same draws for every format
+    losses, step = [], 0
+    while step < steps:
+        for rays, pix in batches:
+            losses.append(nerf_train_step(m, rays, pix, opt, chunk=4096, scheduler=sched))
+            step += 1
+            if step == steps:
+                break
+    losses = [float(l) for l in losses]
+    assert all(l == l for l in losses)
+    m.randomized = False
+    se, n = 0.0, 0
+    with torch.no_grad():
+        for rays, pix in RayBatches(c2w.cuda(), h, w, 70.0, 2.0, 6.0, images=images, batch_size=4096, shuffle=False):
+            rgb = m(rays)[0]
+            se += float(((rgb[-1] - pix) ** 2).sum())
+            n += pix.numel()
+    return float(mse_to_psnr(torch.tensor(se / n))), sum(losses[-20:]) / 20
+
+
+def test_mx_weight_gradient_operands_train_like_bf16_operands():
+    """Convergence A/B of the saved weight-gradient operand formats: the same scene, initial weights, batches and
+    sampling draws, 300 AdamW steps with the reference's learning-rate schedule, three times -- the exact-fp32 path,
+    the bf16 chain with bf16 operand copies, the bf16 chain with MX copies (activations e4m3, gradients block-scaled
+    e2m3).  The MX run must end within 0.2 dB (fine-level PSNR over all pixels) of the bf16-operand run, and both
+    within 1 dB of the fp32 path; the three end points are printed."""
+    out = {}
+    for tag, prec, ops_ in (('fp32', 'fp32', None), ('bf16', 'bf16', 'bf16'), ('mx', 'bf16', 'mx')):
+        out[tag] = _fit_scene(prec, ops_, 300)
+    print('convergence A/B after 300 steps (fine PSNR dB, mean loss of the last 20 steps):',
+          {k: (round(v[0], 3), round(v[1], 6)) for k, v in out.items()})
+    assert abs(out['mx'][0] - out['bf16'][0]) < 0.2, out
+    assert abs(out['bf16'][0] - out['fp32'][0]) < 1.0 and abs(out['mx'][0] - out['fp32'][0]) < 1.0, out
+    assert abs(out['mx'][1] - out['bf16'][1]) < 0.05 * out['bf16'][1], out
+
+
 def _sar_cfg(precision, wavelength, R=2048):
     """The reference's SAR-NeRF hyperparameters (params.yaml:67-93): R rays per chunk, one chunk per pulse."""
     return SimpleNamespace(use_viewdirs=True, randomized=True, ray_shape='cone', num_levels=2, num_samples=180,
@@ -270,6 +328,70 @@ def test_fused_step_matches_the_autograd_step():
         for a, b in zip(out[0][1], out[1][1]):
             assert torch.isfinite(b).all() and float(a.norm()) > 0
             assert float((a - b).norm()) <= 2e-4 * float(a.norm()), n
+
+
+def test_fused_step_with_density_noise_matches_the_autograd_step():
+    """`density_noise > 0` (model.py:135-136: uniform noise on the raw density between the MLP and the compositing)
+    on the fixed launch sequence: with the device generator seeded alike, the fused step draws the jitter and the
+    noise in the reference's order and gives the loss and the gradients of the autograd path; and the noise does
+    change the result."""
+    from nerf_amd.model import MipNeRF
+    from nerf_amd.train import nerf_train_step, synthetic_rays
+    n = 1000
+    torch.manual_seed(4)
+    c = cfg(True)
+    c.density_noise = 0.7
+    m = MipNeRF(c).cuda().train()
+    rays, pix = synthetic_rays(n, 'cuda', seed=8)
+    out = []
+    for fused, noise in ((False, 0.7), (True, 0.7), (True, 0.0)):
+        m.density_noise = noise
+        opt = torch.optim.SGD(m.parameters(), lr=0.0)
+        torch.manual_seed(21)
+        loss = nerf_train_step(m, rays, pix, opt, chunk=n, fused=fused)
+        out.append((float(loss), [p.grad.clone() for p in m.parameters() if p.requires_grad]))
+    assert abs(out[0][0] - out[1][0]) < 1e-5 * abs(out[0][0]), (out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert torch.isfinite(b).all() and float(a.norm()) > 0
+        assert float((a - b).norm()) <= 2e-4 * float(a.norm())
+    assert abs(out[2][0] - out[1][0]) > 1e-4 * abs(out[1][0])
+
+
+def test_graphed_sar_step_follows_the_learning_rate_schedule():
+    """A graph replay must see a changed learning rate (the reference steps MipLRDecay after every optimizer step,
+    model.py:389-393).  A float lr is turned into a device tensor ahead of the capture; three replays at lr 0,
+    1e-3 and 2e-3 (through `step(lr=...)`) move the weights by 0, d and about 2 d; and a scheduler handed to
+    `step` leaves the tensor in place and writes its rate into it."""
+    from bench import make_sar_cfg, sar_batch
+    from nerf_amd.model import SARNeRF
+    from nerf_amd.train import GraphedSarStep
+    from nerf_amd.util_modules import MipLRDecay
+    dev = torch.device('cuda')
+    cfg_ = make_sar_cfg('bf16')
+    cfg_.rays_per_chunk, cfg_.total_num_rays, cfg_.wavelength = 256, 256, 40.0
+    torch.manual_seed(3)
+    m = SARNeRF(cfg_).to(dev).train()
+    # plain SGD-like behaviour of AdamW's first steps: the update is lr * sign-ish(m / sqrt(v)), linear in lr
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.0, fused=True, capturable=True)
+    g = GraphedSarStep(m, sar_batch(dev, seed=7), opt, warmup=2)
+    assert all(torch.is_tensor(gr['lr']) and gr['lr'].is_cuda for gr in opt.param_groups)
+    flat = lambda: torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
+    deltas = []
+    for lr in (0.0, 1e-3, 2e-3):
+        w0 = flat()
+        g.step(lr=lr)
+        torch.cuda.synchronize()
+        deltas.append(float((flat() - w0).norm()))
+    assert deltas[0] == 0.0 and deltas[1] > 0, deltas
+    assert 1.6 < deltas[2] / deltas[1] < 2.4, deltas
+    sched = MipLRDecay(opt, lr_init=1e-2, lr_final=1e-4, max_steps=10, lr_delay_steps=0, lr_delay_mult=1)
+    t = opt.param_groups[0]['lr']
+    g.step(scheduler=sched)
+    assert opt.param_groups[0]['lr'] is t and abs(float(t) - sched.get_last_lr()[0]) < 1e-9
+    assert 1e-4 < float(t) < 1e-2
+    with pytest.raises(RuntimeError):
+        opt.param_groups[0]['lr'] = 1e-3
+        g.step(lr=5e-4)
 
 
 def test_graphed_sar_step_replays_the_eager_step():

@@ -97,7 +97,7 @@ def cosine(a, b):
     return float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize('tag,kw,S,n', CASES[:4])
+@pytest.mark.parametrize('tag,kw,S,n', CASES)
 def test_mlp_backward_chain_exact_structure(tag, kw, S, n):
     """The backward chain and the weight-gradient kernel against the same algebra evaluated in fp32 on the
     kernel's own saved activations (its ReLU decisions) and bf16-rounded operands: every dY within bf16
@@ -362,18 +362,28 @@ def test_e4m3_weight_gradient_operands(tag, kw, S, n):
     assert sorted(worst.values())[len(worst) // 2] < 6e-2
 
 
-@pytest.mark.parametrize('tag,kw,S,n', CASES[:4])
-def test_mlp_gradients_vs_oracle(tag, kw, S, n):
-    """Backward chain + weight-gradient kernels: all 24 parameter gradients against oracle autograd."""
+# Relative Frobenius distance of the MX-operand weight gradients from the bf16-operand ones with WHITE-NOISE upstream
+# gradients on 600 - 2 400 samples, per tensor.  A 3-bit mantissa rounds each gradient element by 2^-4 / sqrt(3) = 3.6 %
+# of its size on average, and a sum of zero-mean terms does not average that away (error and sum both grow as the
+# square root of the count): measured medians 3.3 % - 4.0 %, worst tensors (biases: sums of a few hundred terms) 4.6 % -
+# 10.0 %.  With the gradients of a render, whose terms add coherently, the same distance is 0.1 % - 0.8 %: asserted at
+# 1e-2 on three 1024-ray batches in test_nerf_end_to_end_bf16.
+MX_VS_BF16_WHITE_NOISE_GATE = dict(worst=0.15, median=0.05)
+
+
+@pytest.mark.parametrize('fmt', ['bf16', 'mx'])
+@pytest.mark.parametrize('tag,kw,S,n', CASES)
+def test_mlp_gradients_vs_oracle(tag, kw, S, n, fmt):
+    """Backward chain + weight-gradient kernels: all 24 parameter gradients against oracle autograd, for both
+    formats of the saved weight-gradient operands (bf16 copies; MX copies: activations e4m3, gradients block-scaled
+    e2m3).  The MX run is gated twice: against the oracle by the same direction / norm bounds as the bf16 run, and
+    against the bf16-operand gradients of the same chain by relative Frobenius error per tensor."""
     from nerf_amd import mlp_bf16
     from nerf_amd.model import MipNeRF
     from nerf_amd.utils import Rays
     junk = torch.full((64 << 20,), float('nan'), device='cuda')     # poison the allocator's free pool
     del junk
-    # bf16 copies of the weight-gradient operands: with white-noise upstream gradients on ~2 000 samples the 8-bit
-    # copies add a few per cent of their own (printed by test_e4m3_weight_gradient_operands), which would blur
-    # what this test is about -- the chain and the weight-gradient kernels against the oracle's autograd
-    cfg = make_cfg(wgrad_operands='bf16', **kw)
+    cfg = make_cfg(wgrad_operands=fmt, **kw)
     p = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=5).items()}
     m = MipNeRF(cfg).cuda()
     m.load_state_dict(p, strict=False)
@@ -393,6 +403,21 @@ def test_mlp_gradients_vs_oracle(tag, kw, S, n):
     viewf = mlp_bf16.view_frag(gr.viewdirs, 0, 4)
     d, rgb = mlp_bf16.query_nerf(m, t.cuda(), gr, viewf, S)
     ((d * ga.cuda()).sum() + (rgb * gb.cuda()).sum()).backward()
+    if fmt == 'mx':         # the same chain with bf16 copies: what the 8/6-bit copies alone change
+        got = {k: v.grad.clone() for k, v in m.named_parameters() if not k.endswith('scales')}
+        cfg.wgrad_operands = 'bf16'
+        m.zero_grad(set_to_none=True)
+        d16, rgb16 = mlp_bf16.query_nerf(m, t.cuda(), gr, viewf, S)
+        assert torch.equal(d16, d) and torch.equal(rgb16, rgb)
+        ((d16 * ga.cuda()).sum() + (rgb16 * gb.cuda()).sum()).backward()
+        err = {k: fro(got[k], v.grad) for k, v in m.named_parameters() if not k.endswith('scales')}
+        print(tag, 'mx vs bf16 operands, white-noise upstream: worst %.4f (%s), median %.4f'
+              % (max(err.values()), max(err, key=err.get), sorted(err.values())[len(err) // 2]))
+        assert max(err.values()) < MX_VS_BF16_WHITE_NOISE_GATE['worst'], err
+        assert sorted(err.values())[len(err) // 2] < MX_VS_BF16_WHITE_NOISE_GATE['median'], err
+        for k, v in m.named_parameters():
+            if not k.endswith('scales'):
+                v.grad = got[k]
     for k, v in m.named_parameters():
         if k.endswith('scales'):
             continue
@@ -403,7 +428,9 @@ def test_mlp_gradients_vs_oracle(tag, kw, S, n):
         # (the elementwise-exact check is test_mlp_backward_chain_exact_structure).
         gk, gr = v.grad.cpu(), p[k].grad
         assert cosine(gk, gr) > 0.95, (tag, k, cosine(gk, gr))
-        assert abs(float(gk.norm() / gr.norm()) - 1) < 5e-2, (tag, k)
+        # (MX copies, white-noise upstream: the three-element bias sums carry the gradient rounding undiminished, see
+        # MX_VS_BF16_WHITE_NOISE_GATE; measured up to 8.5 %)
+        assert abs(float(gk.norm() / gr.norm()) - 1) < (5e-2 if fmt == 'bf16' else 0.12), (tag, k)
 
 
 # Relative Frobenius error ||g - ref|| / ||ref|| allowed per gradient tensor against the reference's autograd
@@ -414,11 +441,15 @@ def test_mlp_gradients_vs_oracle(tag, kw, S, n):
 # average rounding errors away.  The 48- and 64-ray fixtures hold 800 - 12 000 samples, so single flips show
 # (measured worst: 9.0 %, 8.6 %, 7.6 %, 7.4 %, always that same tensor; medians 0.6 % - 1.4 %): their bound is
 # the measured figure with headroom, not the gate.
-GRAD_GATE = {'small': 0.12, 'small_det': 0.12, 'small_noview': 0.12, 'c1': 0.10, 'c3': 0.10, 'c3_1k': 2e-2}
+GRAD_GATE = {'small': 0.12, 'small_det': 0.12, 'small_noview': 0.12, 'c1': 0.10, 'c3': 0.10, 'c3_1k': 2e-2,
+             'c3_1k_b': 2e-2, 'yaml_1k': 2e-2}
 GRAD_GATE_FIRST_LAYER_1K = 3.5e-2
+BATCHES_1K = ('c3_1k', 'c3_1k_b', 'yaml_1k')     # 1024 rays: two batches of the 64+128 configuration (different weights,
+                                                  # rays, targets, draws) and the reference's params.yaml configuration
+                                                  # (128+128 samples, max_deg 16)
 
 
-@pytest.mark.parametrize('tag', ['small', 'small_det', 'small_noview', 'c1', 'c3', 'c3_1k'])
+@pytest.mark.parametrize('tag', ['small', 'small_det', 'small_noview', 'c1', 'c3', 'c3_1k', 'c3_1k_b', 'yaml_1k'])
 def test_nerf_end_to_end_bf16(golden, tag):
     """Two-level render with the bf16 MLP against the reference fixtures: colour, depth, acc, loss within 2e-2 (the
     resampled fine level sees bf16-perturbed coarse weights); every parameter gradient by relative Frobenius error
@@ -458,7 +489,7 @@ def test_nerf_end_to_end_bf16(golden, tag):
                 errs[k] = fro(g.reshape(-1)[::max(1, g.numel() // 4096)][:4096], ref)
             else:
                 errs[k] = fro(g.reshape(-1)[::97][:256], T(fx['gslice_' + k]))
-    if tag == 'c3_1k':
+    if tag in BATCHES_1K:
         # the same step with bf16 copies of the weight-gradient operands: the 8-bit copies (the default) move each
         # gradient by well under the 2e-2 gate (one rounding error per operand element, averaged over 196 608 samples)
         assert getattr(cfg, 'wgrad_operands', None) is None
@@ -469,13 +500,19 @@ def test_nerf_end_to_end_bf16(golden, tag):
         m.loss_function(rgb16, T(fx['target']).cuda(), rays.lossmult)[0].backward()
         g8 = {k: g for k, g in zip((k for k, v in m.named_parameters() if not k.endswith('scales')), grads8)}
         fmt_err = {k: fro(g8[k], v.grad) for k, v in m.named_parameters() if not k.endswith('scales')}
-        print('c3_1k e4m3 vs bf16 weight-gradient operands:', {k: round(e, 4) for k, e in fmt_err.items()})
+        print(tag, 'mx vs bf16 weight-gradient operands:', {k: round(e, 4) for k, e in fmt_err.items()})
         assert max(fmt_err.values()) < 1e-2, fmt_err
+        # ... and the bf16-operand step itself against the reference's autograd, by the same gates as the default
+        errs16 = {k: fro(v.grad.cpu().reshape(-1)[::max(1, v.grad.numel() // 4096)][:4096], T(fx['gsample_' + k]))
+                  for k, v in m.named_parameters() if not k.endswith('scales')}
+        print(tag, 'bf16 operands: worst %.4f  median %.4f' % (max(errs16.values()), sorted(errs16.values())[len(errs16) // 2]))
+        for k, e in errs16.items():
+            assert e < (GRAD_GATE_FIRST_LAYER_1K if k == 'density_net0.0.weight' else GRAD_GATE[tag]), (tag, 'bf16', k, e)
     print(tag, 'relative Frobenius error per gradient:', {k: round(e, 4) for k, e in errs.items()})
     print(tag, 'worst %.4f  median %.4f' % (max(errs.values()), sorted(errs.values())[len(errs) // 2]))
     assert len(errs) == (24 if cfg.use_viewdirs else 20)
     for k, e in errs.items():
-        gate = GRAD_GATE_FIRST_LAYER_1K if (tag == 'c3_1k' and k == 'density_net0.0.weight') else GRAD_GATE[tag]
+        gate = GRAD_GATE_FIRST_LAYER_1K if (tag in BATCHES_1K and k == 'density_net0.0.weight') else GRAD_GATE[tag]
         assert e < gate, (tag, k, e)
 
 

@@ -118,7 +118,7 @@ def _rays(fx):
     return O.Rays(*(T(fx['ray_' + k]) for k in ('origins', 'directions', 'viewdirs', 'radii', 'lossmult', 'near', 'far')))
 
 
-@pytest.mark.parametrize('tag', ['small', 'small_det', 'small_noview', 'c1', 'c3'])
+@pytest.mark.parametrize('tag', ['small', 'small_det', 'small_noview', 'c1', 'c3', 'c3_1k', 'c3_1k_b', 'yaml_1k'])
 def test_nerf_end_to_end(golden, tag):
     fx = golden('nerf_e2e_' + tag)
     cfg = cfg_from(fx)
@@ -128,8 +128,9 @@ def test_nerf_end_to_end(golden, tag):
     u_rand = {l: T(fx[f'u_rand_{l}']) for l in range(1, len(levels))} if 't_rand' in fx else None
     out = O.nerf_render(p, _rays(fx), cfg, levels, t_rand, u_rand)
     for l in range(len(levels)):
-        assert relerr(out['t_vals'][l], T(fx[f't_vals_{l}'])) < 1e-5, l
-        assert relerr(out['weights'][l], T(fx[f'weights_{l}'])) < 2e-4, l
+        if f't_vals_{l}' in fx:         # (the 1024-ray fixtures hold no per-sample tensors)
+            assert relerr(out['t_vals'][l], T(fx[f't_vals_{l}'])) < 1e-5, l
+            assert relerr(out['weights'][l], T(fx[f'weights_{l}'])) < 2e-4, l
     assert relerr(out['comp_rgb_stack'], T(fx['rgb'])) < 1e-5
     assert relerr(out['distance_stack'], T(fx['dist'])) < 1e-5
     assert relerr(out['acc_stack'], T(fx['acc'])) < 1e-5

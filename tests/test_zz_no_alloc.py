@@ -67,3 +67,39 @@ def test_static_scatter_matches_the_allocating_entry_point():
     assert L.nerf_scatter_fwd_static(*args) == -3
     args = [null] * 7 + [16, 4, 1 << 20, 0.03, None] + [null] * 9
     assert L.nerf_scatter_fwd_static(*args) == -3
+
+
+def test_static_scatter_replays_from_a_captured_graph():
+    """The use the entry point exists for: after one ordinary call on the device (which looks the library's array
+    up; that lookup is no stream operation and must not happen under capture), the call is captured into a HIP graph
+    with torch.cuda.graph -- nothing in it allocates -- and every replay, on fresh inputs copied into the captured
+    tensors, gives nerf_scatter_fwd's outputs bit for bit."""
+    from nerf_amd import _lib
+    L = _lib.lib()
+    R, S, nsam = 384, 24, 256
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    _call(True, _inputs(R, S, nsam, 3), R, S, nsam)                     # the priming call
+    ins = _inputs(R, S, nsam, 4)
+    dev = 'cuda'
+    out = dict(pulse=torch.zeros(nsam, 2, device=dev), dist=torch.zeros(R, device=dev), acc=torch.zeros(R, device=dev),
+               w=torch.zeros(R, S, device=dev), alpha=torch.zeros(R, S, device=dev),
+               ray_bin=torch.zeros(R, device=dev, dtype=torch.int32), comp=torch.zeros(R, 5, device=dev),
+               status=torch.full((1,), 5, device=dev, dtype=torch.int32))
+    act = _lib.NerfActivation(1, 1e-4, -1.0)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = L.nerf_scatter_fwd_static(*[P(x) for x in ins], R, S, nsam, 0.03, ctypes.byref(act), P(out['pulse']),
+                                       P(out['dist']), P(out['acc']), P(out['w']), P(out['alpha']), P(out['ray_bin']),
+                                       P(out['comp']), P(out['status']), st)
+    assert rc == 0, rc
+    for seed in (4, 5):
+        for dst, src in zip(ins, _inputs(R, S, nsam, seed)):
+            dst.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        want = _call(False, ins, R, S, nsam)
+        assert float(want['pulse'].abs().sum()) > 0
+        for k in want:
+            assert torch.equal(out[k], want[k]), (seed, k)
