@@ -11,7 +11,8 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libnerf_amd.so')
+# (NERF_AMD_LIB: another build of the same library, for A/B timing of kernel variants)
+LIB_PATH = os.environ.get('NERF_AMD_LIB') or os.path.join(_HERE, 'lib', 'libnerf_amd.so')
 
 
 class NerfActivation(Structure):

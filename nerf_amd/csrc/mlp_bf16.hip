@@ -139,6 +139,62 @@ __device__ __forceinline__ void emit_tfrag(bf16x8* dst, int64_t b32, int NT, int
     }
 }
 
+// The same transposition through LDS instead of the matrix pipe (bf16 T-frags only): each lane writes its two pieces
+// (16 bytes each) into a [sample][feature] image of its wave's 32 x 32 tile -- 64-byte rows, the four 16-byte slots of a
+// row XORed with bits 1-2 of the sample, which makes both the writes and the reads conflict-free -- and
+// ds_read_b64_tr_b16 (per 16 lanes: 4 rows x 16 columns of 16-bit elements, delivered column-major) hands every lane
+// the 4 + 4 samples of its feature for each k-step: four 8-byte reads are the two T-frag pieces, bit for bit what the
+// permutation products give (tools/microbench/lds_transpose.hip), without two matrix-core products and eight
+// conversions per tile.  Slot of piece s written by lane half h: 2 s + h (features 16 s + 4 h + {0..3, 8..11});
+// lane 16 g + i of the wave reads, for k-step s and elements 4 e .. 4 e + 3, row 16 s + 8 e + 4 (g >> 1) + (i >> 2),
+// features 16 (g & 1) + 4 (i & 3) .. + 3.  A wave's LDS operations execute in order, so no barrier is involved.
+// Measured (65,536-ray step, bf16 operand copies, one box): forward 14.1 ms and backward 13.4 ms this way against 14.1 and
+// 13.1 ms with the permutation products, and 13.2 / 12.5 ms with no transposition at all (wrong results): the
+// transposition is worth at most 6 % / 4.5 % of these kernels, and the LDS round trip waited for at the end of a tile
+// costs what the two products and eight conversions did.  The product form stays the default.
+#ifndef NERF_TR_LDS
+#define NERF_TR_LDS 0
+#endif
+constexpr int kTrLdsWave = 2048, kTrLds = 8 * kTrLdsWave;       // per wave / per workgroup of 8 waves
+struct TrLds { unsigned wr0, wr1, rd; };
+__device__ __forceinline__ TrLds make_trlds(LDS_AS char* base, int wave, int lane) {
+    const unsigned b = (unsigned)(size_t)base + (unsigned)wave * kTrLdsWave;
+    const int c = lane & 31, h = lane >> 5;
+    const int g = lane >> 4, i = lane & 15, hh = g >> 1, gb = g & 1, q = i >> 2, p = i & 3;
+    TrLds t;
+    t.wr0 = b + 64 * c + 16 * (h ^ ((c >> 1) & 3));
+    t.wr1 = t.wr0 ^ 32u;
+    t.rd = b + 64 * (4 * hh + q) + 16 * ((2 * gb + (p & 1)) ^ (2 * hh + (q >> 1))) + 8 * (p >> 1);
+    return t;
+}
+__device__ __forceinline__ void emit_tfrag_lds(bf16x8* dst, int64_t b32, int NT, int nt, int lane, bf16x8 p0, bf16x8 p1,
+                                               const TrLds& a) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 r0, r1, r2, r3;
+    asm volatile("ds_write_b128 %4, %5\n\tds_write_b128 %6, %7\n\t"
+                 "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %2, %8 offset:1024\n\tds_read_b64_tr_b16 %3, %8 offset:1536\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                 : "v"(a.wr0), "v"(p0), "v"(a.wr1), "v"(p1), "v"(a.rd)
+                 : "memory");
+    const u32x4 o0 = {r0[0], r0[1], r1[0], r1[1]}, o1 = {r2[0], r2[1], r3[0], r3[1]};
+    __builtin_nontemporal_store(__builtin_bit_cast(bf16x8, o0), &dst[tfrag_piece(b32 * 2 + 0, NT, nt) * 64 + lane]);
+    __builtin_nontemporal_store(__builtin_bit_cast(bf16x8, o1), &dst[tfrag_piece(b32 * 2 + 1, NT, nt) * 64 + lane]);
+}
+// bf16 T-frag of one tile by whichever path the build uses
+__device__ __forceinline__ void emit_tfrag_bf16(bf16x8* dst, int64_t b32, int NT, int nt, int lane, bf16x8 p0, bf16x8 p1,
+                                                const bf16x8 (&P)[2], const TrLds& tl) {
+#if NERF_TR_LDS == 2        // (timing experiment: no transposition at all, the pieces stored as they are)
+    __builtin_nontemporal_store(p0, &dst[tfrag_piece(b32 * 2 + 0, NT, nt) * 64 + lane]);
+    __builtin_nontemporal_store(p1, &dst[tfrag_piece(b32 * 2 + 1, NT, nt) * 64 + lane]);
+#elif NERF_TR_LDS
+    emit_tfrag_lds(dst, b32, NT, nt, lane, p0, p1, tl);
+#else
+    emit_tfrag(dst, b32, NT, nt, lane, p0, p1, P);
+#endif
+}
+
 // ---- 8- and 6-bit transposed fragments ("T-frag8", "T-frag6") ------------------------------------------------
 // The weight-gradient operands may be kept in the OCP microscaling element formats instead of bf16 (the chain itself
 // stays bf16): activations as e4m3, 1 byte per element; gradients as e2m3 ("fp6"), 6 bits per element, with one
@@ -495,8 +551,8 @@ enum { EPI_PLAIN = 0, EPI_TRUNK = 1, EPI_HEAD = 2 };
 template <class N, bool SAVE, int STAGE0, int NT, int KS_M, int KS_E, bool RELU, int EPI, int KM, int KE, int KO>
 __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[KM], const bf16x8 (&xe)[KE],
                                           bf16x8 (&out)[KO], const float* bias, int h, bf16x8* tsave,
-                                          unsigned* msave, int64_t b32, const bf16x8 (&P)[2], float (&head)[4],
-                                          float (&ln)[2], bf16x8* fsave = nullptr) {
+                                          unsigned* msave, int64_t b32, const bf16x8 (&P)[2], const TrLds& tl,
+                                          float (&head)[4], float (&ln)[2], bf16x8* fsave = nullptr) {
     constexpr int KS = KS_M + KS_E;
     constexpr bool kMask = SAVE && RELU;
     const int lane = pipe.lane;
@@ -534,7 +590,7 @@ __device__ __forceinline__ void fwd_layer(WeightPipe& pipe, const bf16x8 (&xm)[K
         if (kMask) signs |= tile_sign_bits(pre[0], pre[1]) >> (4 * (nt & 1));
         if (SAVE) {
             if constexpr (N::F8) emit_tfrag8(tsave, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
-            else emit_tfrag(tsave, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
+            else emit_tfrag_bf16(tsave, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P, tl);
         }
         if (SAVE && EPI == EPI_TRUNK && N::SAR) {
 #pragma unroll
@@ -606,6 +662,8 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     const int64_t b32 = blk * 2 + ct;
     bf16x8 P[2];
     make_perm(P, lane);
+    TrLds tl = {0u, 0u, 0u};
+    if constexpr (SAVE && !N::F8) tl = make_trlds((LDS_AS char*)(smem + N::FWD_LDS), wave, lane);
     bf16x8 enc[N::DKS], view[N::VIEW ? N::VKS : 1];
 #pragma unroll
     for (int ks = 0; ks < N::DKS; ++ks) enc[ks] = a.enc[((blk * N::DKS + ks) * 2 + ct) * 64 + lane];
@@ -624,13 +682,13 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
         for (int i = 0; i < (N::DKS + 1) / 2; ++i) {
             const bf16x8 hi = 2 * i + 1 < N::DKS ? enc[2 * i + 1 < N::DKS ? 2 * i + 1 : 0] : zero;
             if constexpr (N::F8) emit_tfrag8(a.t_enc, b32, (N::DKS + 1) / 2, i, lane, enc[2 * i], hi, P);
-            else emit_tfrag(a.t_enc, b32, (N::DKS + 1) / 2, i, lane, enc[2 * i], hi, P);
+            else emit_tfrag_bf16(a.t_enc, b32, (N::DKS + 1) / 2, i, lane, enc[2 * i], hi, P, tl);
         }
 #pragma unroll
         for (int i = 0; i < (N::VKS + 1) / 2; ++i) {      // (no iterations without view directions)
             const bf16x8 hi = 2 * i + 1 < N::VKS ? view[2 * i + 1 < N::VKS ? 2 * i + 1 : 0] : zero;
             if constexpr (N::F8) emit_tfrag8(a.t_view, b32, (N::VKS + 1) / 2, i, lane, view[2 * i], hi, P);
-            else emit_tfrag(a.t_view, b32, (N::VKS + 1) / 2, i, lane, view[2 * i], hi, P);
+            else emit_tfrag_bf16(a.t_view, b32, (N::VKS + 1) / 2, i, lane, view[2 * i], hi, P, tl);
         }
     }
     __syncthreads();
@@ -649,22 +707,22 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     constexpr int HKS = N::HKS, HT = N::HT, HS = stage_count(N::HT), WS = stage_count(N::WT);
     const float* bias = cst + N::C_BIAS;
     // density_net0: enc -> X0 -> X1 -> X2 -> X3
-    fwd_layer<N, SAVE, 0 * HS, HT, 0, N::DKS, true, EPI_PLAIN>(pipe, none, enc, xa, bias + 0 * N::HP, h, a.tx[0], a.mask[0], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, 1 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 1 * N::HP, h, a.tx[1], a.mask[1], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, 2 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 2 * N::HP, h, a.tx[2], a.mask[2], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, 3 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 3 * N::HP, h, a.tx[3], a.mask[3], b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 0 * HS, HT, 0, N::DKS, true, EPI_PLAIN>(pipe, none, enc, xa, bias + 0 * N::HP, h, a.tx[0], a.mask[0], b32, P, tl, hd_density, ln);
+    fwd_layer<N, SAVE, 1 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 1 * N::HP, h, a.tx[1], a.mask[1], b32, P, tl, hd_density, ln);
+    fwd_layer<N, SAVE, 2 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 2 * N::HP, h, a.tx[2], a.mask[2], b32, P, tl, hd_density, ln);
+    fwd_layer<N, SAVE, 3 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 3 * N::HP, h, a.tx[3], a.mask[3], b32, P, tl, hd_density, ln);
     // density_net1: [X3 | enc] -> X4 -> ... -> X7 (trunk output)
-    fwd_layer<N, SAVE, 4 * HS, HT, HKS, N::DKS, true, EPI_PLAIN>(pipe, xb, enc, xa, bias + 4 * N::HP, h, a.tx[4], a.mask[4], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, 5 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 5 * N::HP, h, a.tx[5], a.mask[5], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, 6 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 6 * N::HP, h, a.tx[6], a.mask[6], b32, P, hd_density, ln);
-    fwd_layer<N, SAVE, 7 * HS, HT, HKS, 0, true, EPI_TRUNK>(pipe, xa, none, xb, bias + 7 * N::HP, h, a.tx[7], a.mask[7], b32, P, hd_density, ln, a.x7_frag);
+    fwd_layer<N, SAVE, 4 * HS, HT, HKS, N::DKS, true, EPI_PLAIN>(pipe, xb, enc, xa, bias + 4 * N::HP, h, a.tx[4], a.mask[4], b32, P, tl, hd_density, ln);
+    fwd_layer<N, SAVE, 5 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xa, none, xb, bias + 5 * N::HP, h, a.tx[5], a.mask[5], b32, P, tl, hd_density, ln);
+    fwd_layer<N, SAVE, 6 * HS, HT, HKS, 0, true, EPI_PLAIN>(pipe, xb, none, xa, bias + 6 * N::HP, h, a.tx[6], a.mask[6], b32, P, tl, hd_density, ln);
+    fwd_layer<N, SAVE, 7 * HS, HT, HKS, 0, true, EPI_TRUNK>(pipe, xa, none, xb, bias + 7 * N::HP, h, a.tx[7], a.mask[7], b32, P, tl, hd_density, ln, a.x7_frag);
     // final_density as one more output tile on X7 (row 0; without view directions rows 1..3 are final_rgb and rows
     // 4..5 final_angle: all heads sit on the trunk output)
-    fwd_layer<N, SAVE, 8 * HS, 1, HKS, 0, false, EPI_HEAD>(pipe, xb, none, xw, cst + N::C_BIASD, h, nullptr, nullptr, b32, P, hd_density, ln);
+    fwd_layer<N, SAVE, 8 * HS, 1, HKS, 0, false, EPI_HEAD>(pipe, xb, none, xw, cst + N::C_BIASD, h, nullptr, nullptr, b32, P, tl, hd_density, ln);
     if constexpr (N::VIEW) {
         // rgb_net0 folded into rgb_net1: [X7 | view] -> X9 ; final_rgb (+ final_angle) as one output tile on X9 (rows 0..4)
-        fwd_layer<N, SAVE, 8 * HS + 1, N::WT, HKS, N::VKS, true, EPI_PLAIN>(pipe, xb, view, xw, cst + N::C_BIAS9, h, a.tx[9], a.mask[9], b32, P, hd_colour, ln);
-        fwd_layer<N, SAVE, 8 * HS + 1 + WS, 1, N::WKS, 0, false, EPI_HEAD>(pipe, xw, none, xa, cst + N::C_BIASH, h, nullptr, nullptr, b32, P, hd_colour, ln);
+        fwd_layer<N, SAVE, 8 * HS + 1, N::WT, HKS, N::VKS, true, EPI_PLAIN>(pipe, xb, view, xw, cst + N::C_BIAS9, h, a.tx[9], a.mask[9], b32, P, tl, hd_colour, ln);
+        fwd_layer<N, SAVE, 8 * HS + 1 + WS, 1, N::WKS, 0, false, EPI_HEAD>(pipe, xw, none, xa, cst + N::C_BIASH, h, nullptr, nullptr, b32, P, tl, hd_colour, ln);
         static_assert(fwd_stage<N, SAVE>(8 * HS + 2 + WS).ks == 0 && fwd_stage<N, SAVE>(8 * HS + 1 + WS).ks == N::WKS, "stage table out of step");
     } else {
         static_assert(fwd_stage<N, SAVE>(8 * HS + 1).ks == 0 && fwd_stage<N, SAVE>(8 * HS).ks == HKS, "stage table out of step");
@@ -766,7 +824,7 @@ template <class N, int STAGE0, int NT, int KS_M, int KS_E, bool MASKED, int NW_N
 __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[KM], const bf16x8 (&ge)[KE],
                                           bf16x8 (&out)[KO], const unsigned (&keepw)[KW], const unsigned* next_mask,
                                           unsigned (&nextw)[KWN], bf16x8* tdy, void* tsc, int64_t b32,
-                                          const bf16x8 (&P)[2], const bf16x8 (&x7)[KX] = {}, float c0 = 0.f,
+                                          const bf16x8 (&P)[2], const TrLds& tl, const bf16x8 (&x7)[KX] = {}, float c0 = 0.f,
                                           float c1 = 0.f) {
     constexpr int KS = KS_M + KS_E;
     const int lane = pipe.lane;
@@ -795,7 +853,7 @@ __device__ __forceinline__ void bwd_layer(WeightPipe& pipe, const bf16x8 (&gm)[K
             if constexpr (nt < 4) sc_lo |= e << (8 * nt);
             else sc_hi |= e << (8 * (nt - 4));
         } else {
-            emit_tfrag(tdy, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P);
+            emit_tfrag_bf16(tdy, b32, NT, nt, lane, out[2 * nt], out[2 * nt + 1], P, tl);
         }
     };
     f32x16 prev;
@@ -846,6 +904,8 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
     const bool ok = m < a.M;
     bf16x8 P[2];
     make_perm(P, lane);
+    TrLds tl = {0u, 0u, 0u};
+    if constexpr (!N::F8) tl = make_trlds((LDS_AS char*)(smem + N::BWD_LDS), wave, lane);
     constexpr int HKS = N::HKS, HT = N::HT, WKS = N::WKS, WT = N::WT;
     constexpr int HW = (HT + 1) / 2, WW = (WT + 1) / 2;       // sign words per lane per layer
     constexpr int HS = stage_count(HT), WS = stage_count(WT);
@@ -915,8 +975,8 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
         if constexpr (N::VIEW) store_scales(a.tsc[10], b32, lane, emit_tfrag8_scaled(a.tdy_hd, b32, 1, 0, lane, dz, zero, P), 0u);
         store_scales(a.tsc[11], b32, lane, emit_tfrag8_scaled(a.tdy_dens, b32, 1, 0, lane, N::VIEW ? dd : dz, zero, P), 0u);
     } else {
-        if constexpr (N::VIEW) emit_tfrag(a.tdy_hd, b32, 1, 0, lane, dz, zero, P);
-        emit_tfrag(a.tdy_dens, b32, 1, 0, lane, N::VIEW ? dd : dz, zero, P);
+        if constexpr (N::VIEW) emit_tfrag_bf16(a.tdy_hd, b32, 1, 0, lane, dz, zero, P, tl);
+        emit_tfrag_bf16(a.tdy_dens, b32, 1, 0, lane, N::VIEW ? dd : dz, zero, P, tl);
     }
 
     WeightPipe pipe;
@@ -930,21 +990,21 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(MlpBwdArgs a) {
     bf16x8 ga[HKS], gb[HKS], gw[N::VIEW ? WKS : 1], none[1], dzv[1] = {dz}, ddv[1] = {dd};
     if constexpr (N::VIEW) {
         // heads^T: dX9 = Wh^T dz, masked by X9 > 0 -> dY9
-        bwd_layer<N, 0, WT, 1, 0, true, HW>(pipe, dzv, none, gw, kw9, a.mask[7], kwa, a.tdy[9], a.tsc[9], b32, P);
+        bwd_layer<N, 0, WT, 1, 0, true, HW>(pipe, dzv, none, gw, kw9, a.mask[7], kwa, a.tdy[9], a.tsc[9], b32, P, tl);
         // [folded colour layer (columns of X7 only) ; density head]^T: dX7 = (W9a W8)^T dY9 + wd^T dd, masked by X7 > 0 -> dY7
-        bwd_layer<N, WS, HT, WKS, 1, true, HW, N::SAR>(pipe, gw, ddv, gb, kwa, a.mask[6], kwb, a.tdy[7], a.tsc[7], b32, P, x7, c0, c1);
+        bwd_layer<N, WS, HT, WKS, 1, true, HW, N::SAR>(pipe, gw, ddv, gb, kwa, a.mask[6], kwb, a.tdy[7], a.tsc[7], b32, P, tl, x7, c0, c1);
     } else {
         // head tile^T: dX7 = [wd; Wrgb; Wangle]^T dz, masked by X7 > 0 -> dY7
-        bwd_layer<N, 0, HT, 1, 0, true, HW, N::SAR>(pipe, dzv, none, gb, kwa, a.mask[6], kwb, a.tdy[7], a.tsc[7], b32, P, x7, c0, c1);
+        bwd_layer<N, 0, HT, 1, 0, true, HW, N::SAR>(pipe, dzv, none, gb, kwa, a.mask[6], kwb, a.tdy[7], a.tsc[7], b32, P, tl, x7, c0, c1);
     }
-    bwd_layer<N, WS + 1 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[5], kwa, a.tdy[6], a.tsc[6], b32, P);
-    bwd_layer<N, WS + 2 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[4], kwb, a.tdy[5], a.tsc[5], b32, P);
-    bwd_layer<N, WS + 3 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[3], kwa, a.tdy[4], a.tsc[4], b32, P);
+    bwd_layer<N, WS + 1 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[5], kwa, a.tdy[6], a.tsc[6], b32, P, tl);
+    bwd_layer<N, WS + 2 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[4], kwb, a.tdy[5], a.tsc[5], b32, P, tl);
+    bwd_layer<N, WS + 3 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[3], kwa, a.tdy[4], a.tsc[4], b32, P, tl);
     // density_net1.0^T (rows of X3 only; the encoding needs no gradient)
-    bwd_layer<N, WS + 4 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[2], kwb, a.tdy[3], a.tsc[3], b32, P);
-    bwd_layer<N, WS + 5 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[1], kwa, a.tdy[2], a.tsc[2], b32, P);
-    bwd_layer<N, WS + 6 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[0], kwb, a.tdy[1], a.tsc[1], b32, P);
-    bwd_layer<N, WS + 7 * HS, HT, HKS, 0, true, 0>(pipe, gb, none, ga, kwb, nullptr, nokw, a.tdy[0], a.tsc[0], b32, P);
+    bwd_layer<N, WS + 4 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[2], kwb, a.tdy[3], a.tsc[3], b32, P, tl);
+    bwd_layer<N, WS + 5 * HS, HT, HKS, 0, true, HW>(pipe, gb, none, ga, kwb, a.mask[1], kwa, a.tdy[2], a.tsc[2], b32, P, tl);
+    bwd_layer<N, WS + 6 * HS, HT, HKS, 0, true, HW>(pipe, ga, none, gb, kwa, a.mask[0], kwb, a.tdy[1], a.tsc[1], b32, P, tl);
+    bwd_layer<N, WS + 7 * HS, HT, HKS, 0, true, 0>(pipe, gb, none, ga, kwb, nullptr, nokw, a.tdy[0], a.tsc[0], b32, P, tl);
     static_assert(bwd_stage<N>(WS + 8 * HS).ks == 0 && bwd_stage<N>(WS + 8 * HS - 1).ks != 0, "stage table out of step");
 }
 
@@ -1472,7 +1532,8 @@ static inline bool make_dims(const nerf_mlp_dims* d, HostDims* o) {
 template <class N, bool SAVE, bool FUSE = false>
 static int launch_fwd_t(const MlpFwdArgs& a, hipStream_t st) {
     static std::atomic<unsigned long long> done{0};
-    constexpr int lds = N::FWD_LDS + (FUSE ? kFuseLds : 0);
+    constexpr int lds = N::FWD_LDS + (FUSE ? kFuseLds : 0) + ((SAVE && !N::F8 && NERF_TR_LDS) ? kTrLds : 0);
+    static_assert(lds <= 160 * 1024, "forward chain: LDS beyond the compute unit's 160 KiB");
     if (!allow_dynamic_lds((const void*)mlp_fwd_kernel<N, SAVE, FUSE>, lds, done)) return NERF_ERR_LAUNCH;
     hipLaunchKernelGGL((mlp_fwd_kernel<N, SAVE, FUSE>), dim3((unsigned)(a.nblk / 4)), dim3(64 * kWaves), lds, st, a);
     return nerf_launch_status();
@@ -1488,7 +1549,8 @@ int launch_fwd(const MlpFwdArgs& a, hipStream_t st) {
 template <class N>
 int launch_bwd(const MlpBwdArgs& a, hipStream_t st) {
     static std::atomic<unsigned long long> done{0};
-    constexpr int lds = N::BWD_LDS;
+    constexpr int lds = N::BWD_LDS + ((!N::F8 && NERF_TR_LDS) ? kTrLds : 0);
+    static_assert(lds <= 160 * 1024, "backward chain: LDS beyond the compute unit's 160 KiB");
     if (!allow_dynamic_lds((const void*)mlp_bwd_kernel<N>, lds, done)) return NERF_ERR_LAUNCH;
     hipLaunchKernelGGL((mlp_bwd_kernel<N>), dim3((unsigned)(a.nblk / 4)), dim3(64 * kWaves), lds, st, a);
     return nerf_launch_status();
