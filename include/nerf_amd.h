@@ -350,12 +350,21 @@ typedef struct nerf_wgrad_desc {
     float* gb[2];
     int tfrag_fmt;             /* NERF_TFRAG_BF16 or NERF_TFRAG_MX: the format of dy[] and x[] */
     const void* dy_scale[2];   /* NERF_TFRAG_MX: the scale bytes of dy[] (what nerf_mlp_bwd wrote beside them) */
-    void* workspace;           /* optional (NERF_TFRAG_MX): device scratch for a two-stage flush of the workgroups'
-                                * partial sums instead of float atomics from all of them; 96 MiB covers every shape;
-                                * NULL or too small: atomics.  Its contents mean nothing between calls. */
+    void* workspace;           /* optional: device scratch for a two-stage flush of the workgroups' partial sums
+                                * instead of float atomics from all of them; 128 MiB covers every shape; NULL or too
+                                * small: atomics.  Its contents mean nothing between calls. */
     int64_t workspace_bytes;
 } nerf_wgrad_desc;
 int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint, void* stream);
+
+/* n_desc descriptors (all of one tfrag_fmt) over the same n_samples rows: the result is that of nerf_mlp_wgrad_multi on
+ * each in turn.  In the MX format, when the batch is small (under 4 Mi samples: a rank's shard of a strong-scaled step,
+ * a SAR pulse), consecutive descriptors that use the same kernel instantiation and operand geometry (e.g. the six
+ * 256 x 256 layers of the 8 x 256 network) go out as ONE launch, its workgroups shared out among them: launch gap,
+ * operand-ring fill and the flush of the partial sums are paid once per compute unit instead of once per layer.  The
+ * workspace of the first descriptor of such a run is shared by the run (128 MiB covers every shape).
+ *                              reference: autograd of nn.Linear (aten::mm of dY^T and X, aten::sum), all layers */
+int nerf_mlp_wgrad_batch(const nerf_wgrad_desc* d, int n_desc, int64_t n_samples, void* stream);
 
 /* The mlp_wgrad_kernel<nw, tn, tk, gt> instantiation a weight-gradient launch with these total padded feature
  * counts uses (gt = compile-time loads per wave and k-step, 0 = run-time count), so a profiler can label launches

@@ -51,7 +51,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.inc'))]
     headers.append(os.path.join(os.path.dirname(HERE), 'include', 'nerf_amd.h'))
     headers.append(os.path.abspath(__file__))
     jobs, objs = [], []

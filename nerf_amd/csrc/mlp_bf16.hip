@@ -1024,6 +1024,7 @@ struct WgradArgs {
     int64_t nq;                // 16-sample k-steps
     int NT, KT, WN, WK;        // total tiles per side; waves split the output WN x WK
     int depth;                 // ring slots: depth - 2 k-steps stay in flight
+    float* partial;            // two-stage flush: [workgroup][wave][tile of the wave (+ 1: bias sums)][16][64] or NULL
 };
 
 
@@ -1247,6 +1248,30 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS write may outlive the workgroup
 
+    // Two-stage flush: with every workgroup adding the same 64 K addresses at once the float atomics of a 256 x 256
+    // output take 75-100 us per launch; plain stores of the partial tiles (coalesced, 1 KiB per wave instruction) and
+    // one reduction over the workgroups (wgrad_reduce_kernel) take a third of that.  The bias sums ride in one more tile.
+    if (a.partial != nullptr) {
+        f32x4* pw = (f32x4*)(a.partial + ((int64_t)blockIdx.x * NW + wave) * (NTW * KTW + 1) * 1024);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int j = 0; j < KTW; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const f32x4 x = {acc[i][j][4 * v], acc[i][j][4 * v + 1], acc[i][j][4 * v + 2], acc[i][j][4 * v + 3]};
+                    __builtin_nontemporal_store(x, &pw[((i * KTW + j) * 4 + v) * 64 + lane]);
+                }
+#pragma unroll
+        for (int v = 0; v < (NTW + 3) / 4; ++v) {
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (4 * v + q < NTW) x[q] = accb[4 * v + q];
+            __builtin_nontemporal_store(x, &pw[(NTW * KTW * 4 + v) * 64 + lane]);
+        }
+        return;
+    }
     // flush: accumulator element r of lane l is dW[row n = tile*32 + acc_row(r, l>>5)][col k = tile*32 + (l&31)]
     const int h = lane >> 5, c = lane & 31;
 #pragma unroll
@@ -1275,6 +1300,48 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
     }
 }
 
+
+// Second stage of the two-stage flush: sums the partial tiles of `nwg` workgroups and adds them into the gradients.
+// One thread per (wave, tile, register quad, lane) and slice of workgroups (blockIdx.y of gridDim.y).
+__global__ void wgrad_reduce_kernel(WgradArgs a, int nwg, int NW, int NTW, int KTW) {
+    const int tiles = NTW * KTW + 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NW * tiles * 256) return;
+    const int lane = idx & 63, v = (idx >> 6) & 3, tile = (idx >> 8) % tiles, wave = (idx >> 8) / tiles;
+    const int per = (nwg + gridDim.y - 1) / gridDim.y;
+    const int w0 = blockIdx.y * per, w1 = w0 + per < nwg ? w0 + per : nwg;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    const int64_t stride = (int64_t)NW * tiles * 256;          // f32x4 per workgroup
+    const f32x4* p = (const f32x4*)a.partial + ((int64_t)w0 * NW + wave) * tiles * 256 + (tile * 4 + v) * 64 + lane;
+    for (int w = w0; w < w1; ++w, p += stride) sum += __builtin_nontemporal_load(p);
+    const int wn = wave / a.WK, wk = wave % a.WK;
+    const int h = lane >> 5, c = lane & 31;
+    if (tile < NTW * KTW) {
+        const int i = tile / KTW, j = tile % KTW;
+        const int nt = wn * NTW + i, kt = wk * KTW + j;
+        if (nt >= a.NT || kt >= a.KT) return;
+        const int sa = nt >= a.A[0].tiles, lt = sa ? nt - a.A[0].tiles : nt;
+        const int sb = kt >= a.B[0].tiles, lk = sb ? kt - a.B[0].tiles : kt;
+        const WgradOut o = a.out[sa][sb];
+        const int k = lk * 32 + c;
+        if (o.G == nullptr || k >= a.B[sb].n_true) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nn = lt * 32 + acc_row(4 * v + q, h);
+            if (nn < a.A[sa].n_true) atomicAdd(&o.G[(int64_t)nn * o.ld + o.col0 + k], sum[q]);
+        }
+    } else {            // bias sums: element 4 v + q of the tile is row tile i = 4 v + q of the wave, this lane's feature
+        if (wk != 0) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = 4 * v + q, nt = wn * NTW + i;
+            if (i >= NTW || nt >= a.NT) continue;
+            const int sa = nt >= a.A[0].tiles, lt = sa ? nt - a.A[0].tiles : nt;
+            const int nn = lt * 32 + c;
+            if (a.gb[sa] != nullptr && nn < a.A[sa].n_true) atomicAdd(&a.gb[sa][nn], sum[q]);
+        }
+    }
+}
 
 #endif  // part 7 (continued below: its host side)
 
@@ -1862,22 +1929,15 @@ static int launch_wgrad(const WgradArgs& a, unsigned grid, size_t lds, hipStream
     static std::atomic<unsigned long long> done{0};
     if (!allow_dynamic_lds((const void*)mlp_wgrad_kernel<NW, NTW, KTW, GT>, kWgradLds, done)) return NERF_ERR_LAUNCH;
     hipLaunchKernelGGL((mlp_wgrad_kernel<NW, NTW, KTW, GT>), dim3(grid), dim3(64 * NW), lds, st, a);
+    if (a.partial != nullptr) {
+        const int threads = NW * (NTW * KTW + 1) * 256;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((threads + 255) / 256, grid >= 64 ? 8 : 1), dim3(256), 0, st, a, (int)grid,
+                           NW, NTW, KTW);
+    }
     return nerf_launch_status();
 }
 
-
-// dW blocks for up to two dY buffers x two X buffers in one pass over the samples (each operand byte read once).
-extern "C" int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint, void* stream) {
-    if (n_samples == 0) return NERF_OK;
-    NERF_REQUIRE(d && n_samples > 0);
-    NERF_REQUIRE(d->tfrag_fmt == NERF_TFRAG_BF16 || d->tfrag_fmt == NERF_TFRAG_MX);
-    for (int i = 0; i < 2; ++i) {
-        const int nf = d->dy_feat[i], kf = d->x_feat[i];
-        NERF_REQUIRE(nf >= 0 && kf >= 0 && nf % 32 == 0 && kf % 32 == 0 && (i == 1 || (nf > 0 && kf > 0)));
-        NERF_REQUIRE((nf == 0 || d->dy[i]) && (kf == 0 || d->x[i]) && d->dy_true[i] <= nf && d->x_true[i] <= kf);
-    }
-    NERF_REQUIRE(d->G[0][0] != nullptr);
-    if (d->tfrag_fmt == NERF_TFRAG_MX) return nerf_wgrad8_multi(d, n_samples, grid_hint, nerf_stream(stream));
+static int wgrad_launch(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint, hipStream_t st) {
     WgradArgs a;
     a.NT = a.KT = 0;
     for (int i = 0; i < 2; ++i) {
@@ -1902,15 +1962,17 @@ extern "C" int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples,
     if ((a.depth - 2) * loads > 63) a.depth = 63 / loads + 2;
     if (a.depth < 3) return NERF_ERR_SIZE;
     const size_t lds = (size_t)(a.depth * pieces + nw) * 1024;
-    hipStream_t st = nerf_stream(stream);
+    // two-stage flush when the caller lends a workspace that holds every workgroup's partial tiles and the output is
+    // large enough for the atomics to matter
+    const int64_t need = (int64_t)grid * nw * (tn * tk + 1) * 1024 * 4;
+    a.partial = (d->workspace != nullptr && d->workspace_bytes >= need && tn * tk >= 4) ? (float*)d->workspace : nullptr;
     // the shapes of the 8 x 256 network get the variants with a compile-time load count (loads between the MFMA rows)
-    if (const int gt = wgrad_static_loads(nw, tn, tk, loads)) {
+    if (wgrad_static_loads(nw, tn, tk, loads)) {
         if (nw == 8) return tn == 4 ? launch_wgrad<8, 4, 3, 3>(a, grid, lds, st) : launch_wgrad<8, 5, 2, 3>(a, grid, lds, st);
         if (tn == 4) return launch_wgrad<4, 4, 4, 4>(a, grid, lds, st);
         if (tn == 5) return launch_wgrad<4, 5, 3, 4>(a, grid, lds, st);
         if (tk == 5) return launch_wgrad<4, 2, 5, 4>(a, grid, lds, st);
         if (tn == 2) return launch_wgrad<4, 2, 2, 3>(a, grid, lds, st);
-        (void)gt;
         return launch_wgrad<4, 1, 1, 2>(a, grid, lds, st);
     }
     if (nw == 8) return tn == 4 ? launch_wgrad<8, 4, 3>(a, grid, lds, st) : launch_wgrad<8, 5, 2>(a, grid, lds, st);
@@ -1922,6 +1984,49 @@ extern "C" int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples,
     if (tn == 2 && tk == 5) return launch_wgrad<4, 2, 5>(a, grid, lds, st);
     if (tn == 5 && tk == 3) return launch_wgrad<4, 5, 3>(a, grid, lds, st);
     return launch_wgrad<4, 4, 4>(a, grid, lds, st);
+}
+
+static int wgrad_check_desc(const nerf_wgrad_desc* d) {
+    NERF_REQUIRE(d != nullptr);
+    NERF_REQUIRE(d->tfrag_fmt == NERF_TFRAG_BF16 || d->tfrag_fmt == NERF_TFRAG_MX);
+    for (int i = 0; i < 2; ++i) {
+        const int nf = d->dy_feat[i], kf = d->x_feat[i];
+        NERF_REQUIRE(nf >= 0 && kf >= 0 && nf % 32 == 0 && kf % 32 == 0 && (i == 1 || (nf > 0 && kf > 0)));
+        NERF_REQUIRE((nf == 0 || d->dy[i]) && (kf == 0 || d->x[i]) && d->dy_true[i] <= nf && d->x_true[i] <= kf);
+    }
+    NERF_REQUIRE(d->G[0][0] != nullptr);
+    return NERF_OK;
+}
+
+// dW blocks for up to two dY buffers x two X buffers in one pass over the samples (each operand byte read once).
+extern "C" int nerf_mlp_wgrad_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint, void* stream) {
+    if (n_samples == 0) return NERF_OK;
+    NERF_REQUIRE(n_samples > 0);
+    const int rc = wgrad_check_desc(d);
+    if (rc != NERF_OK) return rc;
+    if (d->tfrag_fmt == NERF_TFRAG_MX) return nerf_wgrad8_multi(d, n_samples, grid_hint, nerf_stream(stream));
+    return wgrad_launch(d, n_samples, grid_hint, nerf_stream(stream));
+}
+
+// Several descriptors at once: the result is that of nerf_mlp_wgrad_multi on each in turn.  In the MX format
+// consecutive descriptors whose launches use the same kernel instantiation and operand geometry go out as ONE launch
+// when the batch is small (wgrad8.hip); bf16 descriptors are launched one by one (their kernels have no registers to
+// spare for picking a descriptor).
+extern "C" int nerf_mlp_wgrad_batch(const nerf_wgrad_desc* d, int n_desc, int64_t n_samples, void* stream) {
+    if (n_samples == 0 || n_desc == 0) return NERF_OK;
+    NERF_REQUIRE(d != nullptr && n_desc > 0 && n_samples > 0);
+    for (int i = 0; i < n_desc; ++i) {
+        const int rc = wgrad_check_desc(&d[i]);
+        if (rc != NERF_OK) return rc;
+        NERF_REQUIRE(d[i].tfrag_fmt == d[0].tfrag_fmt);
+    }
+    hipStream_t st = nerf_stream(stream);
+    if (d[0].tfrag_fmt == NERF_TFRAG_MX) return nerf_wgrad8_batch(d, n_desc, n_samples, st);
+    for (int i = 0; i < n_desc; ++i) {
+        const int rc = wgrad_launch(&d[i], n_samples, 0, st);
+        if (rc != NERF_OK) return rc;
+    }
+    return NERF_OK;
 }
 
 // G[n_true, ld] (+= at column col0, k_true columns) and gb[n_true] (nullable) accumulate dY^T X over

@@ -69,3 +69,4 @@ static inline bool allow_dynamic_lds(const void* fn, int bytes, std::atomic<unsi
 
 // e4m3 weight gradients (wgrad8.hip)
 int nerf_wgrad8_multi(const nerf_wgrad_desc* d, int64_t n_samples, int grid_hint, hipStream_t st);
+int nerf_wgrad8_batch(const nerf_wgrad_desc* d, int n_desc, int64_t n_samples, hipStream_t st);

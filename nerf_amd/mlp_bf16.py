@@ -33,6 +33,7 @@ class WgradDesc(ctypes.Structure):
 
 
 _lib.register('nerf_mlp_wgrad_multi', c_int, [POINTER(WgradDesc), c_int64, c_int, _P])
+_lib.register('nerf_mlp_wgrad_batch', c_int, [POINTER(WgradDesc), c_int, c_int64, _P])
 _lib.register('nerf_mlp_wgrad_config', c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)])
 _lib.register('nerf_mlp_wgrad8_config', c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)])
 _lib.register('nerf_mlp_wgrad', c_int, [_P, c_int, _P, c_int, c_int64, _P, c_int, c_int, c_int, c_int, _P, c_int, _P])
@@ -368,7 +369,6 @@ def mlp_backward(pk, acts, n_samples, g_density, g_rgb, raw_rgb, g_angle=None, r
 
 
 _WGRAD_KERNEL = {}
-WGRAD_GRID = 0          # workgroups per weight-gradient launch; 0 = one per compute unit
 
 
 def wgrad_kernel_name(n_feat, k_feat, fmt=0):
@@ -436,25 +436,30 @@ def mlp_weight_grads(pk, acts, dys, n_samples, grads):
 
 
 _WGRAD_WORKSPACE = {}
-WGRAD_WORKSPACE_BYTES = 96 << 20
+WGRAD_WORKSPACE_BYTES = 128 << 20
 
 
 def _wgrad_workspace(dev):
-    """Scratch for the two-stage flush of the 8-bit weight-gradient launches (one buffer per device, reused by
-    every launch: launches on a stream run one after another)."""
+    """Scratch for the two-stage flush of the weight-gradient launches (one buffer per device, reused by every
+    launch: launches on a stream run one after another)."""
     ws = _WGRAD_WORKSPACE.get(dev)
     if ws is None:
         ws = _WGRAD_WORKSPACE[dev] = torch.empty(WGRAD_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
     return ws
 
 
+WGRAD_BATCHED = True        # launches of one kernel instantiation go out as one launch (nerf_mlp_wgrad_batch)
+
+
 def _wgrad_launches(pk, acts, dys, n_samples, grads):
-    ws = _wgrad_workspace(pk.consts.device) if pk.fmt else None
+    """The weight-gradient launches of one backward pass (see _wgrad_plan), grouped by kernel instantiation: the
+    descriptors of a group go to the library in one call, which runs them as one launch."""
+    ws = _wgrad_workspace(pk.consts.device)
+    groups = {}
     for dsegs, xsegs, blocks in _wgrad_plan(pk):
         d = WgradDesc()
         d.tfrag_fmt = pk.fmt
-        if ws is not None:
-            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
         flops = flops_exec = 0.0
         for i, (di, nf, nt, name) in enumerate(dsegs):
             d.dy[i], d.dy_feat[i], d.dy_true[i] = dys[di].data_ptr(), nf, nt
@@ -478,9 +483,20 @@ def _wgrad_launches(pk, acts, dys, n_samples, grads):
         if pk.fmt:      # (the instantiation depends on the split into segments)
             nf_all, kf_all = tuple(s[1] for s in dsegs), tuple(s[1] for s in xsegs)
         # algorithmic work of the launch: every operand byte once, 2 FLOP per true multiply-add
-        with profiling.timed(wgrad_kernel_name(nf_all, kf_all, pk.fmt), flops=flops, flops_exec=flops_exec,
-                             bytes_=_wgrad_launch_bytes(pk, dsegs, xsegs) * n_samples):
-            check(lib().nerf_mlp_wgrad_multi(ctypes.byref(d), n_samples, WGRAD_GRID, stream()))
+        key = (wgrad_kernel_name(nf_all, kf_all, pk.fmt), nf_all, kf_all) if WGRAD_BATCHED else len(groups)
+        g = groups.setdefault(key, dict(name=key[0] if WGRAD_BATCHED else wgrad_kernel_name(nf_all, kf_all, pk.fmt),
+                                        descs=[], flops=0.0, flops_exec=0.0, bytes=0.0))
+        g['descs'].append(d)
+        g['flops'] += flops
+        g['flops_exec'] += flops_exec
+        g['bytes'] += _wgrad_launch_bytes(pk, dsegs, xsegs) * n_samples
+    for g in groups.values():
+        for lo in range(0, len(g['descs']), 8):             # (a launch carries at most eight descriptors)
+            part = g['descs'][lo:lo + 8]
+            arr = (WgradDesc * len(part))(*part)
+            share = len(part) / len(g['descs'])
+            with profiling.timed(g['name'], flops=g['flops'] * share, flops_exec=g['flops_exec'] * share, bytes_=g['bytes'] * share):
+                check(lib().nerf_mlp_wgrad_batch(arr, len(part), n_samples, stream()))
 
 
 PARAM_NAMES = [n + s for n in STREAMED + ['final_density.0', 'final_rgb.0'] for s in ('.weight', '.bias')]
