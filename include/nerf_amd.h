@@ -204,11 +204,11 @@ int nerf_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, in
                   const float* bias, float* C, int64_t ldc, int64_t M, int N, int64_t K, int act,
                   int split_k, void* stream);
 
-/* C[M,N] (+)= A[M,K] B[K,N] (+ bias[N]) for small products (M * N <= 2^22): one thread per output element, a fixed
- * sequential fp32 summation order, no atomics -- the same bits on every call, which the weight folds at packing time
- * need (their result is rounded to bf16) and which the 128 x 128-tile kernel cannot give when K is split.  accumulate
- * != 0 adds into C.  (No reference counterpart: rgb_net0 and rgb_net1, model.py:78-84, are folded into one matrix
- * here, and these are the products that form it and that split its gradient.) */
+/* C[M,N] (+)= A[M,K] B[K,N] (+ bias[N]) for small products (M * N <= 2^22): eight lanes per output element, each a
+ * sequential fp32 fma chain over every eighth k, the eight sums added in a fixed tree; no atomics -- the same bits on
+ * every call, which the weight folds at packing time need (their result is rounded to bf16) and which the 128 x 128-tile
+ * kernel cannot give when K is split.  accumulate != 0 adds into C.  (No reference counterpart: rgb_net0 and rgb_net1,
+ * model.py:78-84, are folded into one matrix here, and these are the products that form it and that split its gradient.) */
 int nerf_matmul_small_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs,
                           const float* bias, float* C, int64_t ldc, int M, int N, int K, int accumulate, void* stream);
 

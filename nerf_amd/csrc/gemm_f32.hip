@@ -205,31 +205,30 @@ extern "C" int nerf_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const f
     return nerf_launch_status();
 }
 
-// C[m,n] (+)= A[m,:] . B[:,n] (+ bias[n]) by one thread per output element: a sequential fp32 fma chain over K, no
-// atomics, the same bits on every call.  For products far too small to fill the chip with 128 x 128 tiles (the weight
-// folds at packing time: two workgroups of the tile kernel take 120 us over what is 17 MFLOP).
+// C[m,n] (+)= A[m,:] . B[:,n] (+ bias[n]) by eight lanes per output element: lane j runs the fp32 fma chain over
+// k = j, j + 8, ..., and the eight sums are added in a fixed tree ((s0+s1)+(s2+s3))+((s4+s5)+(s6+s7)) by three cross-lane
+// exchanges: no atomics, the same bits on every call.  For products far too small to fill the chip with 128 x 128 tiles
+// (the weight folds at packing time: two workgroups of the tile kernel take 120 us over what is 17 MFLOP; one lane per
+// element with the chains in its own registers took 14-18 us per product, eight take a third).
 __global__ __launch_bounds__(256) void matmul_small_kernel(const float* __restrict__ A, int64_t a_rs, int64_t a_cs,
                                                            const float* __restrict__ B, int64_t b_rs, int64_t b_cs,
                                                            const float* __restrict__ bias, float* __restrict__ C,
                                                            int64_t ldc, int M, int N, int K, int accumulate) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= M * N) return;
-    const int m = idx / N, n = idx - m * N;
+    const int idx = (blockIdx.x * 256 + threadIdx.x) >> 3, j = threadIdx.x & 7;
+    const bool live = idx < M * N;                       // (whole groups of eight lanes: the exchanges below stay inside one)
+    const int e = live ? idx : 0;
+    const int m = e / N, n = e - m * N;
     const float* a = A + m * a_rs;
     const float* b = B + n * b_cs;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // four interleaved chains (fixed association)
-    int k = 0;
-    for (; k + 4 <= K; k += 4) {
-        s0 = fmaf(a[(k + 0) * a_cs], b[(k + 0) * b_rs], s0);
-        s1 = fmaf(a[(k + 1) * a_cs], b[(k + 1) * b_rs], s1);
-        s2 = fmaf(a[(k + 2) * a_cs], b[(k + 2) * b_rs], s2);
-        s3 = fmaf(a[(k + 3) * a_cs], b[(k + 3) * b_rs], s3);
-    }
-    for (; k < K; ++k) s0 = fmaf(a[k * a_cs], b[k * b_rs], s0);
-    float v = (s0 + s1) + (s2 + s3);
-    if (bias != nullptr) v += bias[n];
+    float s = 0.f;
+    for (int k = j; k < K; k += 8) s = fmaf(a[k * a_cs], b[k * b_rs], s);
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    if (!live || j != 0) return;
+    if (bias != nullptr) s += bias[n];
     float* c = C + m * ldc + n;
-    *c = accumulate ? *c + v : v;
+    *c = accumulate ? *c + s : s;
 }
 
 extern "C" int nerf_matmul_small_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs,
@@ -238,7 +237,7 @@ extern "C" int nerf_matmul_small_f32(const float* A, int64_t a_rs, int64_t a_cs,
     if (M == 0 || N == 0) return NERF_OK;
     NERF_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0);
     if ((int64_t)M * N > (1 << 22) || K > 65536) return NERF_ERR_SIZE;      // (nerf_gemm_f32 is the call for larger products)
-    hipLaunchKernelGGL(matmul_small_kernel, dim3((unsigned)(((int64_t)M * N + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(matmul_small_kernel, dim3((unsigned)(((int64_t)M * N * 8 + 255) / 256)), dim3(256), 0,
                        nerf_stream(stream), A, a_rs, a_cs, B, b_rs, b_cs, bias, C, ldc, M, N, K, accumulate ? 1 : 0);
     return nerf_launch_status();
 }

@@ -1347,15 +1347,29 @@ __global__ void wgrad_reduce_kernel(WgradArgs a, int nwg, int NW, int NTW, int K
 
 #if NERF_PART_IS(0)
 // ------------------------------------------------------------------------------------------------
-// Weight packing.  One thread per 16-byte fragment element group.
+// Weight packing.  One thread per 16-byte fragment element group; every matrix of both streams in ONE launch (a table
+// of jobs in the kernel arguments: twenty launches of a few microseconds each were a visible slice of a small step).
 // Forward stream of one layer: pieces [nt][ks], lane (row r = l&31, half h): element j is
 // W[32 nt + r][col(16 ks + frag_feat(j,h))]; the padded k axis is [segment A | segment B].
-__global__ void pack_fwd_kernel(const float* __restrict__ W, int ld, int n_true, int a_true, int a_ks, int b_true,
-                                int b_ks, int NT, bf16x8* __restrict__ dst) {
-    const int KS = a_ks + b_ks;
-    const int total = NT * KS * 64;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+// Backward (transposed) stream of one layer: pieces [kt][s]; lane (row r, half h): element j is
+// W[16 s + frag_feat(j,h)][32 kt + r], rows limited to the first k_true input features; a second matrix may be stacked
+// below the first along the reduction axis (its NS2 k-steps after the first's NS).
+struct PackJob {
+    const float* W;
+    const float* W2;            // backward jobs: the matrix stacked below (NS2 > 0)
+    bf16x8* dst;
+    int ld, ld2, n_true, n2_true;
+    int a_true, a_ks, b_true, b_ks;     // forward jobs: the two segments of the k axis
+    int k_true, NS, NS2;                // backward jobs
+    int tiles;                          // NT (forward) / KT (backward)
+    int backward;
+    int first;                          // index of the job's first element in the launch
+};
+constexpr int kPackJobs = 21;
+struct PackTable { PackJob job[kPackJobs]; int n_jobs, total; };
+
+__device__ __forceinline__ bf16x8 pack_fwd_element(const PackJob& q, int i) {
+    const int KS = q.a_ks + q.b_ks;
     const int lane = i & 63;
     const int ks = (i >> 6) % KS;
     const int nt = (i >> 6) / KS;
@@ -1364,48 +1378,21 @@ __global__ void pack_fwd_kernel(const float* __restrict__ W, int ld, int n_true,
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float v = 0.f;
-        if (n < n_true) {
-            if (ks < a_ks) {
+        if (n < q.n_true) {
+            if (ks < q.a_ks) {
                 const int k = ks * 16 + frag_feat(j, h);
-                if (k < a_true) v = W[(int64_t)n * ld + k];
+                if (k < q.a_true) v = q.W[(int64_t)n * q.ld + k];
             } else {
-                const int k = (ks - a_ks) * 16 + frag_feat(j, h);
-                if (k < b_true) v = W[(int64_t)n * ld + a_true + k];
+                const int k = (ks - q.a_ks) * 16 + frag_feat(j, h);
+                if (k < q.b_true) v = q.W[(int64_t)n * q.ld + q.a_true + k];
             }
         }
         o[j] = (__bf16)v;
     }
-    dst[i] = o;
+    return o;
 }
-
-// Backward (transposed) stream of one layer: pieces [kt][s]; lane (row r, half h): element j is
-// W[16 s + frag_feat(j,h)][32 kt + r], rows limited to the first k_true input features.
-__global__ void pack_bwd_kernel(const float* __restrict__ W, int ld, int n_true, int k_true, int KT, int NS,
-                                bf16x8* __restrict__ dst) {
-    const int total = KT * NS * 64;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int lane = i & 63;
-    const int s = (i >> 6) % NS;
-    const int kt = (i >> 6) / NS;
-    const int k = kt * 32 + (lane & 31), h = lane >> 5;
-    bf16x8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int n = s * 16 + frag_feat(j, h);
-        o[j] = (__bf16)((k < k_true && n < n_true) ? W[(int64_t)n * ld + k] : 0.f);
-    }
-    dst[i] = o;
-}
-
-// As pack_bwd_kernel with a second matrix stacked below the first along the reduction axis.
-__global__ void pack_bwd2_kernel(const float* __restrict__ W, int ld, int n_true, const float* __restrict__ W2,
-                                 int ld2, int n2_true, int k_true, int KT, int NS, int NS2,
-                                 bf16x8* __restrict__ dst) {
-    const int NSS = NS + NS2;
-    const int total = KT * NSS * 64;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+__device__ __forceinline__ bf16x8 pack_bwd_element(const PackJob& q, int i) {
+    const int NSS = q.NS + q.NS2;
     const int lane = i & 63;
     const int s = (i >> 6) % NSS;
     const int kt = (i >> 6) / NSS;
@@ -1414,18 +1401,28 @@ __global__ void pack_bwd2_kernel(const float* __restrict__ W, int ld, int n_true
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float v = 0.f;
-        if (k < k_true) {
-            if (s < NS) {
+        if (k < q.k_true) {
+            if (s < q.NS) {
                 const int n = s * 16 + frag_feat(j, h);
-                if (n < n_true) v = W[(int64_t)n * ld + k];
+                if (n < q.n_true) v = q.W[(int64_t)n * q.ld + k];
             } else {
-                const int n = (s - NS) * 16 + frag_feat(j, h);
-                if (n < n2_true) v = W2[(int64_t)n * ld2 + k];
+                const int n = (s - q.NS) * 16 + frag_feat(j, h);
+                if (n < q.n2_true) v = q.W2[(int64_t)n * q.ld2 + k];
             }
         }
         o[j] = (__bf16)v;
     }
-    dst[i] = o;
+    return o;
+}
+__global__ void pack_kernel(PackTable t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.total) return;
+    int j = 0;
+#pragma unroll 1
+    while (j + 1 < t.n_jobs && i >= t.job[j + 1].first) ++j;
+    const PackJob& q = t.job[j];
+    const int e = i - q.first;
+    q.dst[e] = q.backward ? pack_bwd_element(q, e) : pack_fwd_element(q, e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1679,25 +1676,22 @@ extern "C" int nerf_mlp_pack(const nerf_mlp_dims* dims, const float* const* weig
     bf16x8* f = (bf16x8*)wfwd;
     bf16x8* b = (bf16x8*)wbwd;
     const int HKS = 2 * d.HT;
+    PackTable t = {};
     auto pf = [&](const float* W, int ld, int n_true, int a_true, int a_ks, int b_true, int b_ks, int NT) {
+        PackJob& q = t.job[t.n_jobs++];
+        q = PackJob{W, nullptr, f, ld, 0, n_true, 0, a_true, a_ks, b_true, b_ks, 0, 0, 0, NT, 0, t.total};
         const int total = NT * (a_ks + b_ks) * 64;
-        hipLaunchKernelGGL(pack_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W, ld, n_true, a_true, a_ks,
-                           b_true, b_ks, NT, f);
         f += total;
+        t.total += total;
     };
-    auto pb = [&](const float* W, int ld, int n_true, int k_true, int KT, int NS) {
-        const int total = KT * NS * 64;
-        hipLaunchKernelGGL(pack_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W, ld, n_true, k_true, KT, NS,
-                           b);
-        b += total;
-    };
-    // second form: the reduction axis is [rows of W (NS k-steps) | rows of W2 (NS2 k-steps)]
-    auto pb2 = [&](const float* W, int ld, int n_true, const float* W2, int ld2, int n2_true, int k_true, int KT,
-                   int NS, int NS2) {
+    // the reduction axis is [rows of W (NS k-steps) | rows of W2 (NS2 k-steps, 0 = none)]
+    auto pb = [&](const float* W, int ld, int n_true, const float* W2, int ld2, int n2_true, int k_true, int KT, int NS,
+                  int NS2) {
+        PackJob& q = t.job[t.n_jobs++];
+        q = PackJob{W, W2, b, ld, ld2, n_true, n2_true, 0, 0, 0, 0, k_true, NS, NS2, KT, 1, t.total};
         const int total = KT * (NS + NS2) * 64;
-        hipLaunchKernelGGL(pack_bwd2_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W, ld, n_true, W2, ld2,
-                           n2_true, k_true, KT, NS, NS2, b);
         b += total;
+        t.total += total;
     };
     const bool view = d.V > 0;
     const int n_head = d.sar ? 5 : 3;
@@ -1714,16 +1708,18 @@ extern "C" int nerf_mlp_pack(const nerf_mlp_dims* dims, const float* const* weig
     if (wbwd != nullptr) {
         // consumption order of the backward chain: heads, colour layer, 7, ..., 1 (layer 0 needs no input gradient)
         if (view) {
-            pb(weights[10], d.W, n_head, d.W, d.WT, 1);                      // heads^T: dX9 = Wh^T dZ, one k-step
+            pb(weights[10], d.W, n_head, nullptr, 0, 0, d.W, d.WT, 1, 0);     // heads^T: dX9 = Wh^T dZ, one k-step
             // [folded colour layer (its X7 columns) ; density head]^T
-            pb2(weights[8], d.H + d.V, d.W, weights[9], d.H, 1, d.H, d.HT, 2 * d.WT, 1);
+            pb(weights[8], d.H + d.V, d.W, weights[9], d.H, 1, d.H, d.HT, 2 * d.WT, 1);
         } else {
-            pb(weights[9], d.H, 1 + n_head, d.H, d.HT, 1);                   // head tile^T: dX7 = Whd^T dZ, one k-step
+            pb(weights[9], d.H, 1 + n_head, nullptr, 0, 0, d.H, d.HT, 1, 0);  // head tile^T: dX7 = Whd^T dZ, one k-step
         }
-        for (int i = 7; i >= 5; --i) pb(weights[i], d.H, d.H, d.H, d.HT, HKS);
-        pb(weights[4], d.H + d.D, d.H, d.H, d.HT, HKS);
-        for (int i = 3; i >= 1; --i) pb(weights[i], d.H, d.H, d.H, d.HT, HKS);
+        for (int i = 7; i >= 5; --i) pb(weights[i], d.H, d.H, nullptr, 0, 0, d.H, d.HT, HKS, 0);
+        pb(weights[4], d.H + d.D, d.H, nullptr, 0, 0, d.H, d.HT, HKS, 0);
+        for (int i = 3; i >= 1; --i) pb(weights[i], d.H, d.H, nullptr, 0, 0, d.H, d.HT, HKS, 0);
     }
+    static_assert(11 + 9 <= kPackJobs, "job table too small");
+    hipLaunchKernelGGL(pack_kernel, dim3((t.total + 255) / 256), dim3(256), 0, st, t);
     return nerf_launch_status();
 }
 

@@ -142,27 +142,19 @@ class Packed(Geom):
         check(lib().nerf_mlp_pack(ctypes.byref(self.dims), arr, _raw(self.wfwd),
                                   _raw(self.wbwd) if need_bwd else None, stream()))
 
-        # fp32 constants block (layout: Net::C_* in mlp_bf16.hip)
-        c = torch.zeros(nc.value, dtype=torch.float32, device=dev)
-        for i, n in enumerate(STREAMED[:8]):
-            c[i * HP:i * HP + H] = p[n + '.bias']
-        o = 8 * HP
+        # fp32 constants block (layout: Net::C_* in mlp_bf16.hip): the pieces are concatenated once and gathered into
+        # place through an index map that is fixed per geometry (two launches where one slice assignment per piece
+        # was a dozen to three dozen small copies per packing)
+        pieces = [p[n + '.bias'] for n in STREAMED[:8]]                 # -> i * HP .. i * HP + H
         if self.view:
-            c[o:o + W] = bias9
-        o += WP
+            pieces.append(bias9)                                        # -> 8 HP .. + W
         if not self.sar:
-            c[o] = bd[0]
-        if not self.view:
-            c[o + 1:o + 1 + head_bias.numel()] = head_bias
-        o += 32
-        if self.view:
-            c[o:o + head_bias.numel()] = head_bias
-        o += 32
+            pieces.append(bd.reshape(1))                                # -> row 0 of the density head tile
+        pieces.append(head_bias)                                        # -> rows 1.. of the head tile / the colour head tile
         if self.sar:
-            c[o + 6] = self.head_density.sum()
-            c[o + 7] = (wd[0] * beta).sum() + bd[0]
-            c[o + 8:o + 9].fill_(1.0 / H)        # (fill_: a kernel argument, where item assignment of a Python
-            c[o + 9:o + 10].fill_(1e-5)          # number copies from host memory, which a graph capture refuses)
+            pieces += [self.head_density.sum().reshape(1), ((wd[0] * beta).sum() + bd[0]).reshape(1)]
+        idx, fixed = _consts_map(self, nc.value, dev, head_bias.numel())
+        c = torch.cat([f32c(x).reshape(-1) for x in pieces] + [fixed]).index_select(0, idx)
         self.consts = c
         # algorithmic work per sample (true layer sizes): forward MACs, input-gradient MACs (no gradient
         # w.r.t. the encodings), weight-gradient MACs; bytes = bf16 operands the weight-gradient pass must read
@@ -182,6 +174,43 @@ class Packed(Geom):
         self.bwd_dx_flops_exec = 2.0 * (macs_dx - fold)
         # bf16 operand bytes per sample that the weight-gradient launches read (see _wgrad_plan)
         self.wgrad_bytes = sum(_wgrad_launch_bytes(self, dys, xs) for dys, xs, _ in _wgrad_plan(self))
+
+
+_CONSTS_MAP = {}
+
+
+def _consts_map(g, n_consts, dev, n_head_bias):
+    """Where each float of the constants block comes from in the concatenation Packed builds: an int64 index per float
+    (device tensor, cached per geometry) and the three fixed values [0, 1/H, LayerNorm eps] that end the concatenation."""
+    key = (tuple(g.ints()), str(dev))
+    if key not in _CONSTS_MAP:
+        H, W, HP, WP = g.H, g.W, 32 * g.HT, 32 * g.WT
+        src = 0
+        pos = {}                                    # destination -> source
+        for i in range(8):
+            pos.update({i * HP + k: src + k for k in range(H)})
+            src += H
+        o = 8 * HP
+        if g.view:
+            pos.update({o + k: src + k for k in range(W)})
+            src += W
+        o += WP
+        if not g.sar:
+            pos[o] = src
+            src += 1
+        ob = o + 1 if not g.view else o + 32       # head biases: behind the density row, or the colour head tile
+        pos.update({ob + k: src + k for k in range(n_head_bias)})
+        src += n_head_bias
+        o += 64
+        if g.sar:
+            pos[o + 6], pos[o + 7] = src, src + 1
+            src += 2
+            pos[o + 8], pos[o + 9] = src + 1, src + 2
+        idx = torch.full((n_consts,), src, dtype=torch.int64)          # default: the zero
+        for dst, s_ in pos.items():
+            idx[dst] = s_
+        _CONSTS_MAP[key] = (idx.to(dev), torch.tensor([0.0, 1.0 / H, 1e-5], dtype=torch.float32).to(dev))
+    return _CONSTS_MAP[key]
 
 
 def _wgrad_plan(pk):
