@@ -323,7 +323,8 @@ def main():
         out = {'value': rays_per_rank * world * args.steps / dt, 'ms_per_step': dt / args.steps * 1e3,
                'rays_per_step_per_gpu': rays_per_rank, 'global_rays_per_step': rays_per_rank * world, 'loss': loss}
         if prof:
-            per, roof, util, util_exec = roofline_of(prof, args.steps, rays_per_rank, operands, args.chunk < rays_per_rank)
+            per, roof, util, util_exec = roofline_of(prof, args.steps, rays_per_rank, operands,
+                                                     args.workload == 'c3' and args.chunk < rays_per_rank)
             out.update(kernel_ms_per_step=per, roofline=roof)
             if util is not None:
                 out.update(mlp_mfma_util=util, mlp_mfma_util_executed=util_exec)

@@ -440,14 +440,17 @@ def fold_gradients(pk, grads):
     grads['rgb_net1.0.bias'].add_(s)
 
 
-def mlp_weight_grads(pk, acts, dys, n_samples, grads):
-    """Accumulate all weight / bias gradients into `grads` (name -> zero-initialised or running fp32 tensor)."""
+def mlp_weight_grads(pk, acts, dys, n_samples, grads, after_trunk=None):
+    """Accumulate all weight / bias gradients into `grads` (name -> zero-initialised or running fp32 tensor).
+    `after_trunk()` (optional) is called once the launches that write the trunk layers' gradients (density_net0 /
+    density_net1: nine tenths of the bytes) are queued and before the remaining ones: a multi-rank caller starts
+    their all-reduce there, under the rest of the pass."""
     dev = pk.consts.device
     grads = dict(grads)
     if not pk.view:
         hd_w, hd_b = torch.zeros(8, pk.H, device=dev), torch.zeros(8, device=dev)
         grads['_hd.weight'], grads['_hd.bias'] = hd_w, hd_b
-        _wgrad_launches(pk, acts, dys, n_samples, grads)
+        _wgrad_launches(pk, acts, dys, n_samples, grads, after_trunk)
         if pk.sar:      # (the caller assembles the LayerNorm / density gradients from these, see _MlpSar)
             grads['_dens.weight'][0].add_(hd_w[0])
             grads['_dens.bias'][1:3].add_(hd_b[6:8])
@@ -460,7 +463,7 @@ def mlp_weight_grads(pk, acts, dys, n_samples, grads):
             grads['final_rgb.0.bias'].add_(hd_b[1:4])
         return
     grads['_g98.weight'], grads['_g98.bias'] = torch.zeros(pk.W, pk.H, device=dev), torch.zeros(pk.W, device=dev)
-    _wgrad_launches(pk, acts, dys, n_samples, grads)
+    _wgrad_launches(pk, acts, dys, n_samples, grads, after_trunk)
     fold_gradients(pk, grads)
 
 
@@ -480,12 +483,14 @@ def _wgrad_workspace(dev):
 WGRAD_BATCHED = True        # launches of one kernel instantiation go out as one launch (nerf_mlp_wgrad_batch)
 
 
-def _wgrad_launches(pk, acts, dys, n_samples, grads):
+def _wgrad_launches(pk, acts, dys, n_samples, grads, after_trunk=None):
     """The weight-gradient launches of one backward pass (see _wgrad_plan), grouped by kernel instantiation: the
-    descriptors of a group go to the library in one call, which runs them as one launch."""
+    descriptors of a group go to the library in one call, which runs them as one launch.  The groups that write
+    only trunk gradients go first; `after_trunk()` is called between them and the rest."""
     ws = _wgrad_workspace(pk.consts.device)
     groups = {}
     for dsegs, xsegs, blocks in _wgrad_plan(pk):
+        trunk = all(blk is None or blk[0].startswith('density_net') for row in blocks for blk in row)
         d = WgradDesc()
         d.tfrag_fmt = pk.fmt
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -512,20 +517,26 @@ def _wgrad_launches(pk, acts, dys, n_samples, grads):
         if pk.fmt:      # (the instantiation depends on the split into segments)
             nf_all, kf_all = tuple(s[1] for s in dsegs), tuple(s[1] for s in xsegs)
         # algorithmic work of the launch: every operand byte once, 2 FLOP per true multiply-add
-        key = (wgrad_kernel_name(nf_all, kf_all, pk.fmt), nf_all, kf_all) if WGRAD_BATCHED else len(groups)
-        g = groups.setdefault(key, dict(name=key[0] if WGRAD_BATCHED else wgrad_kernel_name(nf_all, kf_all, pk.fmt),
+        key = (trunk, wgrad_kernel_name(nf_all, kf_all, pk.fmt), nf_all, kf_all) if WGRAD_BATCHED else len(groups)
+        g = groups.setdefault(key, dict(name=wgrad_kernel_name(nf_all, kf_all, pk.fmt), trunk=trunk,
                                         descs=[], flops=0.0, flops_exec=0.0, bytes=0.0))
         g['descs'].append(d)
         g['flops'] += flops
         g['flops_exec'] += flops_exec
         g['bytes'] += _wgrad_launch_bytes(pk, dsegs, xsegs) * n_samples
-    for g in groups.values():
+    signalled = after_trunk is None
+    for g in sorted(groups.values(), key=lambda g: not g['trunk']):
+        if not g['trunk'] and not signalled:
+            after_trunk()
+            signalled = True
         for lo in range(0, len(g['descs']), 8):             # (a launch carries at most eight descriptors)
             part = g['descs'][lo:lo + 8]
             arr = (WgradDesc * len(part))(*part)
             share = len(part) / len(g['descs'])
             with profiling.timed(g['name'], flops=g['flops'] * share, flops_exec=g['flops_exec'] * share, bytes_=g['bytes'] * share):
                 check(lib().nerf_mlp_wgrad_batch(arr, len(part), n_samples, stream()))
+    if not signalled:
+        after_trunk()
 
 
 PARAM_NAMES = [n + s for n in STREAMED + ['final_density.0', 'final_rgb.0'] for s in ('.weight', '.bias')]

@@ -88,10 +88,11 @@ class NerfStepper:
         lo = 64 * self.blk0[l]
         return t[lo:lo + self.n * S]
 
-    def step(self, rays, pixels, global_mask_sum=None, t_rand=None, u_rand=None, noise=None):
+    def step(self, rays, pixels, global_mask_sum=None, t_rand=None, u_rand=None, noise=None, after_trunk=None):
         """Forward + loss + backward of one batch; the weight gradients are ADDED into the parameters' `.grad`
         (views of the caller's gradient bucket).  -> loss (device scalar), comp_rgb [L,N,3] (this step's buffers).
-        `t_rand`, `u_rand`, `noise` as in MipNeRF.forward: pre-drawn random tensors in place of the device draws."""
+        `t_rand`, `u_rand`, `noise` as in MipNeRF.forward: pre-drawn random tensors in place of the device draws.
+        `after_trunk`: see mlp_bf16.mlp_weight_grads (where a multi-rank step starts reducing the trunk gradients)."""
         model, n, dev = self.model, self.n, self.dev
         cfg = model.config
         assert rays.origins.shape[0] == n
@@ -146,7 +147,7 @@ class NerfStepper:
         n_real = n * sum(self.levels)
         mlp_bf16.mlp_backward(pk, self.acts, m_all, self.g_density, self.g_rgb, self.raw_rgb, dys=self.dys, n_real=n_real)
         grads = {k: q.grad for k, q in model.named_parameters() if q.requires_grad}
-        mlp_bf16.mlp_weight_grads(pk, self.acts, self.dys, m_all, grads)
+        mlp_bf16.mlp_weight_grads(pk, self.acts, self.dys, m_all, grads, after_trunk)
         sq = self.ray_sq.sum(dim=1) * self.inv_mask_sum
         return cwd * sq[:-1].sum() + sq[-1], self.comp
 

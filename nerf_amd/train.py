@@ -24,7 +24,8 @@ def synthetic_rays(n, device, seed=0, normalize=True):
 class GradBucket:
     """One persistent, contiguous buffer (the parameters' dtype, fp32 for the render models) that holds every gradient: each parameter's `.grad` is a view into
     it, so the weight-gradient kernels accumulate straight into the bucket and the step needs exactly one
-    collective on it, with no gather before and no scatter after.  Views start on 256-byte boundaries (the
+    collective on it (or two on its two parts, when the first part is reduced while the second is still being
+    computed), with no gather before and no scatter after.  Views start on 256-byte boundaries (the
     padding stays zero and rides along in the collective)."""
 
     ALIGN = 64          # floats
@@ -54,11 +55,23 @@ class GradBucket:
         self.attach()
         self.flat.zero_()
 
-    def all_reduce(self, world_size, async_op=False):
-        """SUM over ranks, in place (RCCL on GPUs, gloo on CPU); returns the work handle when `async_op`."""
+    def all_reduce(self, world_size, async_op=False, lo=0, hi=None):
+        """SUM over ranks, in place (RCCL on GPUs, gloo on CPU), of the whole bucket or of its floats lo .. hi; returns
+        the work handle when `async_op`."""
         if world_size <= 1:
             return None
-        return _all_reduce_sum(self.flat, async_op=async_op)
+        return _all_reduce_sum(self.flat if (lo == 0 and hi is None) else self.flat[lo:hi], async_op=async_op)
+
+    def prefix_end(self, named_params, prefix):
+        """End (in floats) of the leading run of parameters whose names start with `prefix` (0 if the first does not):
+        the part of the bucket that is complete once those parameters' gradients are."""
+        names = {id(p): k for k, p in named_params}
+        end = 0
+        for p, v in zip(self.params, self.views):
+            if not names.get(id(p), '').startswith(prefix):
+                break
+            end = v.storage_offset() + -(-p.numel() // self.ALIGN) * self.ALIGN
+        return min(end, self.flat.numel())
 
 
 def grad_bucket(model_or_params):
@@ -127,8 +140,19 @@ def nerf_train_step(model, rays, pixels, optimizer, chunk=8192, world_size=1, gl
     bucket.zero()
     from . import stepper
     if fused and chunk >= n and n > 0 and stepper.supported(model):
-        total, _ = stepper.stepper_for(model, n).step(rays, pixels, global_mask_sum)
-        return _finish_step(model, bucket, optimizer, scheduler, world_size, total)
+        # Several ranks: the trunk layers' gradients (the leading nine tenths of the bucket) are reduced as soon as
+        # their weight-gradient launches are queued, under the remaining launches; the collective runs on the
+        # backend's own stream behind what the compute stream holds at that point (the mechanism bucketed data
+        # parallelism overlaps with), and the rest of the bucket follows at the end of the pass.
+        early = {}
+
+        def reduce_trunk():
+            hi = bucket.prefix_end(model.named_parameters(), 'density_net')
+            if world_size > 1 and hi > 0:
+                early['hi'], early['work'] = hi, bucket.all_reduce(world_size, async_op=True, lo=0, hi=hi)
+        total, _ = stepper.stepper_for(model, n).step(rays, pixels, global_mask_sum,
+                                                      after_trunk=reduce_trunk if world_size > 1 else None)
+        return _finish_step(model, bucket, optimizer, scheduler, world_size, total, early)
     total = torch.zeros((), device=rays.origins.device)
     cwd = model.loss_function.coarse_weight_decay
     import contextlib
@@ -147,11 +171,13 @@ def nerf_train_step(model, rays, pixels, optimizer, chunk=8192, world_size=1, gl
     return _finish_step(model, bucket, optimizer, scheduler, world_size, total)
 
 
-def _finish_step(model, bucket, optimizer, scheduler, world_size, total):
+def _finish_step(model, bucket, optimizer, scheduler, world_size, total, early=None):
     bucket.attach()
-    work = bucket.all_reduce(world_size, async_op=True)
-    if work is not None:
-        work.wait()             # orders the collective ahead of the optimizer kernels on the current stream
+    lo = early.get('hi', 0) if early else 0           # floats 0 .. lo are already being reduced (nerf_train_step)
+    work = bucket.all_reduce(world_size, async_op=True, lo=lo, hi=None if lo == 0 else bucket.flat.numel())
+    for w in ((early or {}).get('work'), work):
+        if w is not None:
+            w.wait()            # orders the collective ahead of the optimizer kernels on the current stream
     optimizer.step()
     if scheduler is not None:
         scheduler.step()

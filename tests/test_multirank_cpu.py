@@ -55,7 +55,14 @@ def _worker(rank, world, port, n, q):
     _shard_loss(p, rays, tgt, cfg, lo, hi, mask_sum).backward()
     bucket.attach()
     assert all(x.grad.data_ptr() == v.data_ptr() for x, v in zip(params, bucket.views))
-    bucket.all_reduce(world)
+    # as the fused step reduces it: the trunk layers' leading part of the bucket first (started while the rest of the
+    # weight-gradient pass is still running), then the remainder; together the whole bucket, once
+    split = bucket.prefix_end(list(p.items()), 'density_net')
+    assert 0 < split < bucket.flat.numel() and split == sum(-(-v.numel() // 64) * 64 for k, v in p.items() if k.startswith('density_net'))
+    works = [bucket.all_reduce(world, async_op=True, lo=0, hi=split),
+             bucket.all_reduce(world, async_op=True, lo=split, hi=bucket.flat.numel())]
+    for w in works:
+        w.wait()
     q.put((rank, lo, hi, [x.grad.numpy().copy() for x in params]))     # by value: the worker may exit first
     dist.barrier()
     dist.destroy_process_group()

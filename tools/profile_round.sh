@@ -16,3 +16,6 @@ for f in bf16 mx; do
 done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4 -o c4 -- python3 bench.py --workload c4 --graph off --steps 25 --warmup 5 > $O/bench_c4_profiled.json 2> $O/stats_c4.err
 find $O -name "*.csv" | head -40
+# summaries (copy what is to be judged into profiles/ afterwards)
+python3 tools/pmc_summary.py $O/pmc_traffic.json bf16 $(find $O/pmc_fetch_bf16 -name "*counter_collection.csv") $(find $O/pmc_write_bf16 -name "*counter_collection.csv") mx $(find $O/pmc_fetch_mx -name "*counter_collection.csv") $(find $O/pmc_write_mx -name "*counter_collection.csv") > $O/pmc_traffic.txt
+for f in bf16 mx; do python3 tools/chain_counters.py $(find $O/pmc_busy_$f -name "*counter_collection.csv") $O/chain_counters_$f.json > $O/chain_counters_$f.txt; done
