@@ -1137,11 +1137,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_wgrad_kernel(WgradArgs a)
             });
 #pragma unroll
             for (int j = 0; j < KTW; ++j) acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ii], B[j], acc[ii][j], 0, 0, 0);
-            const u32x4 d = __builtin_bit_cast(u32x4, A[ii]);
-            float t = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) t += __uint_as_float(d[q] << 16) + __uint_as_float(d[q] & 0xffff0000u);
-            accb[ii] += t;
+            // (one v_dot2c_f32_bf16 against a pair of ones per register: fp32 sum of the two halves.  Unpacking the
+            // halves by shift and mask took 17 vector instructions per tile instead of 4 and 11 % of the pass; these
+            // four take 5 %; dealing the rows to the waves that share them, behind a wave-uniform branch, was slower.)
+            const bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
+            accb[ii] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(A[ii], A[ii], 0, 1), ones, accb[ii], false);
+            accb[ii] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(A[ii], A[ii], 2, 3), ones, accb[ii], false);
+            accb[ii] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(A[ii], A[ii], 4, 5), ones, accb[ii], false);
+            accb[ii] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(A[ii], A[ii], 6, 7), ones, accb[ii], false);
             if constexpr (GT > 0) __builtin_amdgcn_sched_barrier(0);
         });
     };

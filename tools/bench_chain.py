@@ -1,9 +1,8 @@
-"""Time the fused MLP forward (inference / training) and backward chain on C3-shaped input."""
+"""Time the fused MLP forward (inference / training), backward chain and weight-gradient pass on C3-shaped input.
+NERF_FMT=bf16|mx picks the format of the saved operands, NERF_AMD_LIB another build of the library, NERF_ZERO=1 zero weights."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import nerf_amd._lib as _L
-if os.environ.get('NERF_LIB'): _L.LIB_PATH = os.environ['NERF_LIB']
 from bench import make_cfg
 from nerf_amd.model import MipNeRF
 from nerf_amd import mlp_bf16
@@ -43,8 +42,3 @@ grads = {k: torch.zeros_like(v) for k, v in m.named_parameters()}
 ms = timeit(lambda: mlp_bf16.mlp_weight_grads(pk, acts, dys, M, grads))
 print(f"wgrad: {ms:.3f} ms  {pk.wgrad_bytes * M / ms / 1e6:.0f} GB/s", flush=True)
 
-if os.environ.get('NERF_GRID_SWEEP'):
-  for grid in (256, 192, 128, 96, 64):
-    mlp_bf16.WGRAD_GRID = grid
-    ms = timeit(lambda: mlp_bf16.mlp_weight_grads(pk, acts, dys, M, grads))
-    print(f"wgrad grid {grid}: {ms:.3f} ms  {pk.wgrad_bytes * M / ms / 1e6:.0f} GB/s", flush=True)
