@@ -188,6 +188,17 @@ int nerf_scatter_bwd(const float* rgb, const float* angle, const float* density,
                      int num_samples, int nsam, float wavelength, const nerf_activation* act,
                      float* g_rgb, float* g_angle, float* g_density, void* stream);
 
+/* SAR pulse post-processing and loss, forward and gradient, in one launch (model.py:377-380: matched filter by
+ * zero-padded FFT, crop, division by the pulse's standard deviation; util_modules.py:74-89: per-level mean squared
+ * error against the measured pulse, loss = coarse_weight * sum(mse[:-1]) + mse[-1]).
+ *   pulse[levels, nsam, 2]  range profiles as (re, im) pairs     mfilt[nfft, 2]  the filter's spectrum
+ *   target[nsam, 2]         the measured pulse                   profile[levels, nsam, 2] (nullable)  z / std(z)
+ *   level_mse[levels]       per-level mean squared error         g_pulse[levels, nsam, 2] (nullable)  d loss / d pulse
+ * nfft a power of two <= 8192, 2 <= nsam <= nfft (NERF_ERR_SIZE otherwise: callers then use an FFT library).
+ * One workgroup per level; the first call on a device raises the kernel's LDS limit and must not be captured. */
+int nerf_sar_pulse_loss(const float* pulse, const float* mfilt, const float* target, int levels, int nsam, int nfft,
+                        float coarse_weight, float* profile, float* level_mse, float* g_pulse, void* stream);
+
 /* ---- (b) MLP, full-precision path ---------------------------------------------------- */
 
 #define NERF_ACT_NONE 0

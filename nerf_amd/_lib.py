@@ -57,6 +57,7 @@ _SIGS = {
     'nerf_colsum_f32': (c_int, [_P, c_int64, c_int64, c_int, _P, _P]),
     'nerf_layernorm_fwd': (c_int, [_P, _P, _P, c_int64, c_int, c_float, _P, _P, _P, _P]),
     'nerf_layernorm_bwd': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P]),
+    'nerf_sar_pulse_loss': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -25,6 +25,7 @@ UNITS = {
     'api.o': ('api.hip', []),
     'sampling.o': ('sampling.hip', ['-ffp-contract=off']),
     'composite.o': ('composite.hip', ['-ffp-contract=off']),
+    'sar_pulse.o': ('sar_pulse.hip', []),
     'gemm_f32.o': ('gemm_f32.hip', []),
     # VGPR-form matrix-core instructions where an accumulator tile lives in the vector registers: the outputs of the
     # larger launches exceed the 256 accumulation registers, and the default form copies such tiles in and out

@@ -232,3 +232,30 @@ def scatter(rgb, angle, density, power, t_vals, dirs, pulse_bins, wavelength, ac
     r, s = t_vals.shape[0], t_vals.shape[1] - 1
     return _Scatter.apply(rgb.reshape(r, s, 3), angle.reshape(r, s, 2), density.reshape(r, s), power.reshape(r),
                           t_vals, dirs.reshape(r, 3), pulse_bins.reshape(-1), wavelength, tuple(act))
+
+
+SAR_PULSE_MAX_FFT = 8192
+
+
+def sar_pulse_supported(nsam, nfft):
+    """Sizes nerf_sar_pulse_loss takes: the filter's length a power of two up to 8192, 2 <= nsam <= nfft."""
+    return 2 <= nsam <= nfft <= SAR_PULSE_MAX_FFT and nfft & (nfft - 1) == 0
+
+
+def sar_pulse_loss(pulse, mfilt, target, coarse_weight, need_grad=True, need_profile=False):
+    """Matched filter, normalisation and loss of one pulse (model.py:377-380, util_modules.py:74-89) in one launch.
+    pulse [L, nsam, 2] range profiles, mfilt [nfft] complex64 (or [1, nfft]), target [nsam, 2] (or [1, nsam, 2])
+    -> (loss, level_mse [L], profile [L, nsam, 2] or None, g_pulse [L, nsam, 2] = d loss / d pulse or None)."""
+    levels, nsam = pulse.shape[0], pulse.shape[1]
+    mf = torch.view_as_real(mfilt.reshape(-1).to(torch.complex64)).contiguous()
+    nfft = mf.shape[0]
+    dev = pulse.device
+    pulse, tg = f32c(pulse), f32c(target.reshape(nsam, 2))
+    mse = torch.empty(levels, device=dev)
+    profile = torch.empty(levels, nsam, 2, device=dev) if need_profile else None
+    g = torch.empty(levels, nsam, 2, device=dev) if need_grad else None
+    check(lib().nerf_sar_pulse_loss(ptr(pulse), ptr(mf), ptr(tg), levels, nsam, nfft, float(coarse_weight),
+                                    ptr(profile) if need_profile else None, ptr(mse), ptr(g) if need_grad else None,
+                                    stream()))
+    loss = coarse_weight * mse[:-1].sum() + mse[-1]
+    return loss, mse, profile, g

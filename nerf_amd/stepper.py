@@ -271,16 +271,21 @@ class SarStepper:
             from .train import _all_reduce_sum
             for x in comp:
                 _all_reduce_sum(x)
-        # matched filter, per-pulse normalisation and loss through autograd, with the range profiles as leaves
-        leaves = [x.requires_grad_(True) for x in comp]
+        # matched filter, per-pulse normalisation, loss and the gradient of the range profiles: one launch when the
+        # filter's length is a power of two up to 8192, else torch.fft (rocFFT) and autograd with the profiles as leaves
         mf = mfilt.to(dev)
-        outs = []
-        for l in range(L):                                                                     # model.py:377-380
-            zc = torch.view_as_complex(leaves[l][None].contiguous())
-            zc = torch.fft.ifft(mf * torch.fft.fft(zc, mf.shape[-1], dim=-1), dim=-1)[..., :nsam]
-            outs.append(torch.view_as_real(zc / torch.std(zc, dim=-1)[..., None]))
-        loss, _ = model.loss_function.level_losses(torch.stack(outs), target.to(dev))
-        g_comp = torch.autograd.grad(loss, leaves)
+        cwd = float(model.loss_function.coarse_weight_decay)
+        if ops.sar_pulse_supported(nsam, mf.shape[-1]) and mf.numel() == mf.shape[-1]:
+            loss, _, _, g_comp = ops.sar_pulse_loss(torch.stack(comp), mf, target.to(dev), cwd)
+        else:
+            leaves = [x.requires_grad_(True) for x in comp]
+            outs = []
+            for l in range(L):                                                                 # model.py:377-380
+                zc = torch.view_as_complex(leaves[l][None].contiguous())
+                zc = torch.fft.ifft(mf * torch.fft.fft(zc, mf.shape[-1], dim=-1), dim=-1)[..., :nsam]
+                outs.append(torch.view_as_real(zc / torch.std(zc, dim=-1)[..., None]))
+            loss, _ = model.loss_function.level_losses(torch.stack(outs), target.to(dev))
+            g_comp = torch.autograd.grad(loss, leaves)
         for q, (ray_p, t_vals, ray_d, ray_bin, comp5, dist, dens) in enumerate(saved):
             lo = 64 * q * self.nblk
             sl = lambda t: t[lo:lo + M]

@@ -278,6 +278,48 @@ def test_scatter_out_of_range_flag(ops, golden):
     assert int(out[-1]) == -4
 
 
+@pytest.mark.parametrize('levels,nsam,nfft', [(2, 2048, 8192), (2, 256, 512), (1, 37, 64), (3, 64, 64), (2, 2, 2)])
+def test_sar_pulse_loss_vs_oracle(ops, levels, nsam, nfft):
+    """Matched filter, normalisation, loss and gradient in one launch against the oracle's torch.fft chain and its
+    autograd, both evaluated in double precision on the same fp32 inputs (the oracle's chain itself is pinned by the
+    reference's end-to-end SAR fixtures): profiles, per-level errors, loss and gradient within fp32 rounding of a
+    13-stage transform."""
+    g = torch.Generator().manual_seed(levels * 1000 + nsam)
+    pulse = torch.randn(levels, nsam, 2, generator=g) * 3e4           # the scale of summed ray returns
+    mf = torch.complex(torch.randn(1, nfft, generator=g), torch.randn(1, nfft, generator=g))
+    target = torch.randn(1, nsam, 2, generator=g)
+    cwd = 0.1
+    leaf = pulse.double().requires_grad_(True)
+    want = torch.stack([O.pulse_postprocess(torch.view_as_complex(leaf[l][None]), mf.to(torch.complex128), nsam)[0]
+                        for l in range(levels)])
+    want_loss, _ = O.sar_loss(want[:, None], target.double(), cwd)
+    want_g, = torch.autograd.grad(want_loss, leaf)
+    loss, mse, prof, grad = ops.sar_pulse_loss(pulse.cuda(), mf.cuda(), target.cuda(), cwd, need_profile=True)
+    assert relerr(prof.cpu(), want.detach().float()) < 2e-5
+    assert abs(float(loss) - float(want_loss.detach())) < 1e-5 * abs(float(want_loss.detach()))
+    want_mse = ((want.detach() - target.double()) ** 2).mean(dim=(1, 2))
+    assert relerr(mse.cpu(), want_mse.float()) < 1e-5
+    assert relerr(grad.cpu(), want_g.float()) < 5e-5
+    # forward only: no gradient buffer, the same errors
+    loss2, mse2, _, none = ops.sar_pulse_loss(pulse.cuda(), mf.cuda(), target.cuda(), cwd, need_grad=False)
+    assert none is None and torch.equal(mse2, mse)
+
+
+def test_sar_pulse_loss_refuses_other_sizes(ops):
+    from nerf_amd import _lib
+    z = torch.zeros(1, 8, 2, device='cuda')
+    for nsam, nfft in ((8, 12), (8, 16384), (8, 4), (1, 8)):
+        assert not ops.sar_pulse_supported(nsam, nfft)
+    import ctypes
+    m = torch.zeros(1, device='cuda')
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    L = _lib.lib()
+    assert L.nerf_sar_pulse_loss(P(z), P(z), P(z), 1, 8, 12, 0.1, None, P(m), None, None) == -3      # NERF_ERR_SIZE
+    assert L.nerf_sar_pulse_loss(P(z), P(z), P(z), 1, 8, 4, 0.1, None, P(m), None, None) == -3
+    assert L.nerf_sar_pulse_loss(P(z), P(z), P(z), 1, 1, 8, 0.1, None, P(m), None, None) == -1       # NERF_ERR_ARG
+    assert L.nerf_sar_pulse_loss(P(z), None, P(z), 1, 8, 8, 0.1, None, P(m), None, None) == -1
+
+
 def test_empty_inputs(ops):
     z = torch.empty(0, 5, device='cuda')
     assert ops.stratified_t(z[:, :1], z[:, :1], 4).shape == (0, 5)
