@@ -440,7 +440,7 @@ def fold_gradients(pk, grads):
     grads['rgb_net1.0.bias'].add_(s)
 
 
-def mlp_weight_grads(pk, acts, dys, n_samples, grads, after_trunk=None):
+def mlp_weight_grads(pk, acts, dys, n_samples, grads, after_trunk=None, grid_hint=0, workspace=None):
     """Accumulate all weight / bias gradients into `grads` (name -> zero-initialised or running fp32 tensor).
     `after_trunk()` (optional) is called once the launches that write the trunk layers' gradients (density_net0 /
     density_net1: nine tenths of the bytes) are queued and before the remaining ones: a multi-rank caller starts
@@ -450,7 +450,7 @@ def mlp_weight_grads(pk, acts, dys, n_samples, grads, after_trunk=None):
     if not pk.view:
         hd_w, hd_b = torch.zeros(8, pk.H, device=dev), torch.zeros(8, device=dev)
         grads['_hd.weight'], grads['_hd.bias'] = hd_w, hd_b
-        _wgrad_launches(pk, acts, dys, n_samples, grads, after_trunk)
+        _wgrad_launches(pk, acts, dys, n_samples, grads, after_trunk, grid_hint, workspace)
         if pk.sar:      # (the caller assembles the LayerNorm / density gradients from these, see _MlpSar)
             grads['_dens.weight'][0].add_(hd_w[0])
             grads['_dens.bias'][1:3].add_(hd_b[6:8])
@@ -463,7 +463,7 @@ def mlp_weight_grads(pk, acts, dys, n_samples, grads, after_trunk=None):
             grads['final_rgb.0.bias'].add_(hd_b[1:4])
         return
     grads['_g98.weight'], grads['_g98.bias'] = torch.zeros(pk.W, pk.H, device=dev), torch.zeros(pk.W, device=dev)
-    _wgrad_launches(pk, acts, dys, n_samples, grads, after_trunk)
+    _wgrad_launches(pk, acts, dys, n_samples, grads, after_trunk, grid_hint, workspace)
     fold_gradients(pk, grads)
 
 
@@ -483,11 +483,13 @@ def _wgrad_workspace(dev):
 WGRAD_BATCHED = True        # launches of one kernel instantiation go out as one launch (nerf_mlp_wgrad_batch)
 
 
-def _wgrad_launches(pk, acts, dys, n_samples, grads, after_trunk=None):
+def _wgrad_launches(pk, acts, dys, n_samples, grads, after_trunk=None, grid_hint=0, workspace=None):
     """The weight-gradient launches of one backward pass (see _wgrad_plan), grouped by kernel instantiation: the
     descriptors of a group go to the library in one call, which runs them as one launch.  The groups that write
-    only trunk gradients go first; `after_trunk()` is called between them and the rest."""
-    ws = _wgrad_workspace(pk.consts.device)
+    only trunk gradients go first; `after_trunk()` is called between them and the rest.  `grid_hint` > 0: that many
+    workgroups per launch (a pass that shares the chip with another stream), each descriptor a launch of its own;
+    `workspace`: the scratch of the two-stage flush (passes that run side by side need one each)."""
+    ws = workspace if workspace is not None else _wgrad_workspace(pk.consts.device)
     groups = {}
     for dsegs, xsegs, blocks in _wgrad_plan(pk):
         trunk = all(blk is None or blk[0].startswith('density_net') for row in blocks for blk in row)
@@ -534,7 +536,11 @@ def _wgrad_launches(pk, acts, dys, n_samples, grads, after_trunk=None):
             arr = (WgradDesc * len(part))(*part)
             share = len(part) / len(g['descs'])
             with profiling.timed(g['name'], flops=g['flops'] * share, flops_exec=g['flops_exec'] * share, bytes_=g['bytes'] * share):
-                check(lib().nerf_mlp_wgrad_batch(arr, len(part), n_samples, stream()))
+                if grid_hint > 0:
+                    for d in part:
+                        check(lib().nerf_mlp_wgrad_multi(ctypes.byref(d), n_samples, int(grid_hint), stream()))
+                else:
+                    check(lib().nerf_mlp_wgrad_batch(arr, len(part), n_samples, stream()))
     if not signalled:
         after_trunk()
 
