@@ -362,6 +362,37 @@ def test_e4m3_weight_gradient_operands(tag, kw, S, n):
     assert sorted(worst.values())[len(worst) // 2] < 6e-2
 
 
+@pytest.mark.parametrize('fmt', ['bf16', 'mx'])
+def test_weight_gradient_pass_on_fewer_workgroups_with_its_own_workspace(fmt):
+    """`mlp_weight_grads(grid_hint=, workspace=)`: the pass on 48 workgroups per launch (a pass that shares the chip
+    with another stream) and with a caller-owned scratch buffer gives the gradients of the default pass, up to the
+    order of its fp32 partial sums."""
+    from nerf_amd import mlp_bf16
+    from nerf_amd.model import MipNeRF
+    tag, kw, S, n = CASES[1]
+    cfg = make_cfg(wgrad_operands=fmt, **kw)
+    m = MipNeRF(cfg).cuda()
+    m.load_state_dict(O.init_params(cfg, seed=5), strict=False)
+    rays = make_rays(n, 3)
+    g = torch.Generator().manual_seed(4)
+    t = O.stratified_t(rays.near, rays.far, S, torch.rand(n, S + 1, generator=g))
+    M = n * S
+    pk = mlp_bf16.packed_for(m, True)
+    encf = mlp_bf16.encode_frag(t.cuda(), rays.origins.cuda(), rays.directions.cuda(), rays.radii.cuda(), 'cone',
+                                cfg.min_deg, cfg.max_deg)
+    viewf = mlp_bf16.view_frag(rays.viewdirs.cuda(), 0, 4)
+    d, rgbk, _, acts, _ = mlp_bf16.mlp_forward(pk, encf, viewf, M, S, n, save=True)
+    dys = mlp_bf16.mlp_backward(pk, acts, M, torch.randn(M, generator=g).cuda(), torch.randn(M, 3, generator=g).cuda(), rgbk)
+    out = []
+    for hint, ws in ((0, None), (48, torch.empty(mlp_bf16.WGRAD_WORKSPACE_BYTES, dtype=torch.uint8, device='cuda')), (3, None)):
+        grads = {k: torch.zeros_like(v) for k, v in m.named_parameters() if v.requires_grad}
+        mlp_bf16.mlp_weight_grads(pk, acts, dys, M, grads, grid_hint=hint, workspace=ws)
+        out.append(grads)
+    for other in out[1:]:
+        for k, a in out[0].items():
+            assert float(a.norm()) > 0 and fro(other[k], a) < 1e-4, k
+
+
 # Relative Frobenius distance of the MX-operand weight gradients from the bf16-operand ones with WHITE-NOISE upstream
 # gradients on 600 - 2 400 samples, per tensor.  A 3-bit mantissa rounds each gradient element by 2^-4 / sqrt(3) = 3.6 %
 # of its size on average, and a sum of zero-mean terms does not average that away (error and sum both grow as the
