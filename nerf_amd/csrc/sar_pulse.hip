@@ -19,7 +19,7 @@
 namespace {
 
 constexpr int kThreads = 1024;
-constexpr int kMaxFft = 8192;                  // 64 KiB of samples + 32 KiB of twiddles in LDS
+constexpr int kMaxFft = 8192;                  // 64 KiB of samples + 64 KiB of twiddle tables in LDS
 constexpr int kPerThread = kMaxFft / kThreads; // samples a thread keeps in registers between the transforms
 
 struct cf { float re, im; };
@@ -41,16 +41,19 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 }
 
 // d[0 .. n) -> crop(ifft(filter * fft(d)))[0 .. n), in place in LDS; `filt` in global memory, conjugated if CONJ.
-// On entry d[n .. nfft) must be zero.  tw[k] = exp(-2 pi i k / nfft), k < nfft / 2.
+// On entry d[n .. nfft) must be zero.  tw holds one table per stage, the stage of half-size m at offset m - 1:
+// tw[m - 1 + j] = exp(-2 pi i j / (2 m)), j < m -- consecutive lanes read consecutive entries (one table indexed with
+// a stride of nfft / 2 m put a whole wave on one or two LDS banks in the middle stages, and the kernel took twice as long).
 template <bool CONJ>
 __device__ __forceinline__ void filter_in_lds(cf* d, const cf* tw, const cf* __restrict__ filt, int nfft, int log2n) {
     const int half = nfft >> 1;
-    for (int m = half, sh = 0; m >= 1; m >>= 1, ++sh) {            // decimation in frequency: blocks of 2 m
+    for (int m = half; m >= 1; m >>= 1) {                          // decimation in frequency: blocks of 2 m
+        const cf* t = tw + (m - 1);
         for (int b = threadIdx.x; b < half; b += kThreads) {
             const int j = b & (m - 1), i = ((b - j) << 1) + j;
             const cf a = d[i], c = d[i + m];
             d[i] = a + c;
-            d[i + m] = cmul(a - c, tw[j << sh]);
+            d[i + m] = cmul(a - c, t[j]);
         }
         __syncthreads();
     }
@@ -60,10 +63,11 @@ __device__ __forceinline__ void filter_in_lds(cf* d, const cf* tw, const cf* __r
         d[i] = cmul(d[i], CONJ ? conj(f) : f);
     }
     __syncthreads();
-    for (int m = 1, sh = log2n - 1; m < nfft; m <<= 1, --sh) {     // decimation in time, conjugate twiddles
+    for (int m = 1; m < nfft; m <<= 1) {                           // decimation in time, conjugate twiddles
+        const cf* t = tw + (m - 1);
         for (int b = threadIdx.x; b < half; b += kThreads) {
             const int j = b & (m - 1), i = ((b - j) << 1) + j;
-            const cf a = d[i], c = cmul(d[i + m], conj(tw[j << sh]));
+            const cf a = d[i], c = cmul(d[i + m], conj(t[j]));
             d[i] = a + c;
             d[i + m] = a - c;
         }
@@ -86,10 +90,11 @@ __global__ __launch_bounds__(kThreads) void sar_pulse_loss_kernel(const float* _
     const cf* tg = (const cf*)target;
     const float inv_n = 1.0f / (float)nfft;
 
-    for (int k = threadIdx.x; k < (nfft >> 1); k += kThreads) {
+    for (int e = threadIdx.x; e < nfft - 1; e += kThreads) {       // entry e = m - 1 + j of the stage tables, m a power of two
+        const int m = 1 << (31 - __clz(e + 1)), j = e + 1 - m;
         float s, c;
-        sincospif(-2.0f * (float)k * inv_n, &s, &c);
-        tw[k] = {c, s};
+        sincospif(-(float)j / (float)m, &s, &c);                   // -2 pi j / (2 m)
+        tw[e] = {c, s};
     }
     for (int i = threadIdx.x; i < nfft; i += kThreads) d[i] = i < nsam ? x[i] : cf{0.f, 0.f};
     __syncthreads();
@@ -164,13 +169,13 @@ extern "C" int nerf_sar_pulse_loss(const float* pulse, const float* mfilt, const
     if (nfft > kMaxFft || (nfft & (nfft - 1)) != 0 || nsam > nfft) return NERF_ERR_SIZE;
     int log2n = 0;
     while ((1 << log2n) < nfft) ++log2n;
-    const int lds = nfft * 8 + nfft * 4;
+    const int lds = nfft * 16;                                      // samples + stage tables (nfft - 1 entries)
     static std::atomic<unsigned long long> done{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return NERF_ERR_LAUNCH;
     if (!(done.load(std::memory_order_acquire) & (1ull << dev))) {     // once per device: dynamic LDS beyond 64 KiB
         if (hipFuncSetAttribute((const void*)sar_pulse_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kMaxFft * 12) != hipSuccess)
+                                kMaxFft * 16) != hipSuccess)
             return NERF_ERR_LAUNCH;
         done.fetch_or(1ull << dev, std::memory_order_release);
     }
