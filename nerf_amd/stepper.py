@@ -194,8 +194,17 @@ class SarStepper:
         z = lambda *shape: torch.zeros(*shape, device=dev)      # (padding samples of a pass stay zero: no gradient)
         self.raw_density, self.raw_rgb, self.raw_angle, self.ln_stats = z(m_all), z(m_all, 3), z(m_all, 2), z(m_all, 2)
         self.g_density, self.g_rgb, self.g_angle = z(m_all), z(m_all, 3), z(m_all, 2)
-        self.dens_w, self.dens_b = z(3, pk.H), z(3)
-        self.heads_w, self.heads_b = z(5, pk.W if pk.view else pk.H), z(5)
+        # scratch of the weight-gradient pass (sums the head gradients are assembled from), one buffer, one fill per step
+        hw = pk.W if pk.view else pk.H
+        shapes = {'_dens.weight': (3, pk.H), '_dens.bias': (3,), '_heads.weight': (5, hw), '_heads.bias': (5,)}
+        shapes.update({'_g98.weight': (pk.W, pk.H), '_g98.bias': (pk.W,)} if pk.view else
+                      {'_hd.weight': (8, pk.H), '_hd.bias': (8,)})
+        sizes = {k: -(-int(torch.Size(v).numel()) // 64) * 64 for k, v in shapes.items()}      # 256-byte aligned pieces
+        self.scratch = z(sum(sizes.values()))
+        self.scratch_grads, off = {}, 0
+        for k, shp in shapes.items():
+            self.scratch_grads[k] = self.scratch[off:off + int(torch.Size(shp).numel())].view(shp)
+            off += sizes[k]
 
     def _slice(self, bufs, per_block, q):
         lo, hi = q * self.nblk, (q + 1) * self.nblk
@@ -301,13 +310,10 @@ class SarStepper:
                               self.raw_angle, self.ln_stats, dys=self.dys, n_real=M * self.passes)
         P = {k: v.detach() for k, v in model.named_parameters()}
         grads = {k: q.grad for k, q in model.named_parameters() if q.requires_grad}
-        for t in (self.dens_w, self.dens_b, self.heads_w, self.heads_b):
-            t.zero_()
-        grads.update({'_dens.weight': self.dens_w, '_dens.bias': self.dens_b, '_heads.weight': self.heads_w,
-                      '_heads.bias': self.heads_b})
+        self.scratch.zero_()
+        grads.update(self.scratch_grads)
         mlp_bf16.mlp_weight_grads(pk, self.acts, self.dys, m_all, grads)
-        for k, g in mlp_bf16.sar_head_gradients(P, grads).items():
-            grads[k].add_(g)
+        mlp_bf16.add_sar_head_gradients(P, grads)
         return loss.detach()
 
 
