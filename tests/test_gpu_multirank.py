@@ -87,6 +87,61 @@ def test_two_rank_rccl_step_matches_one_rank():
     assert np.array_equal(got[0][2], got[1][2])
 
 
+def _nccl_single_worker(port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    assert dist.get_backend() == 'nccl'
+    from nerf_amd.model import MipNeRF
+    from nerf_amd.train import nerf_train_step, synthetic_rays
+    dev = torch.device('cuda', 0)
+    out = []
+    for world in (1, 2):            # 2: every collective of the multi-rank step is issued (over the group's one rank)
+        torch.manual_seed(0)
+        m = MipNeRF(_cfg()).to(dev).train()
+        rays, pix = synthetic_rays(4096, dev, seed=9)
+        opt = torch.optim.SGD(m.parameters(), lr=0.0)
+        loss = nerf_train_step(m, rays, pix, opt, chunk=4096, world_size=world)
+        out.append((float(loss), torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.requires_grad]).cpu().numpy()))
+    # the other collectives bench.py issues around the step: parameter broadcast, max of the ranks' times, barrier
+    for p in m.parameters():
+        dist.broadcast(p.data, 0)
+    tmax = torch.tensor([1.25], device=dev, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    assert float(tmax) == 1.25
+    dist.barrier()
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    q.put(out)
+
+
+def test_one_rank_rccl_group_runs_the_collective_path():
+    """What a one-GPU box can check of the RCCL path: in a one-rank `nccl` group the multi-rank step (mask-sum
+    all-reduce, the trunk gradients' asynchronous all-reduce issued from inside the weight-gradient pass, the rest of
+    the bucket, both waited for ahead of the optimizer, a barrier) runs on the real backend and, the sums being over
+    one rank, leaves the loss and the gradients of the plain step."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    pr = ctx.Process(target=_nccl_single_worker, args=(port, q))
+    pr.start()
+    try:
+        (loss1, g1), (loss2, g2) = q.get(timeout=240)
+    finally:
+        pr.join(60)
+        if pr.is_alive():
+            pr.kill()
+    assert pr.exitcode == 0
+    assert abs(loss1 - loss2) <= 1e-6 * abs(loss1)
+    assert np.isfinite(g2).all() and np.linalg.norm(g2 - g1) <= 1e-4 * np.linalg.norm(g1)
+
+
 def test_bench_launches_its_own_ranks():
     """`bench.py --gpus 2` with no launcher around it starts two ranks itself and rank 0 prints one JSON line with
     n_gpus 2.  With two GPUs this is the RCCL path; on a one-GPU box both ranks share cuda:0 over gloo (a rehearsal
