@@ -41,21 +41,26 @@ def test_c3_gradients_do_not_depend_on_chunking():
 
 
 def test_c2_forward_does_not_depend_on_chunking_and_stays_in_range():
-    """Rays are independent: rendering 262 144 rays at once or 8 192 at a time gives identical pixels
-    (deterministic sampling); acc in [0, 1], colour within the padded sigmoid range, distance within [near, far]."""
+    """C2 at its full size.  Rays are independent: rendering 1 048 576 rays at once or 8 192 at a time gives identical
+    pixels (deterministic sampling); acc in [0, 1], colour within the padded sigmoid range, distance within [near, far];
+    and every ray of the big batch equals the same ray rendered in a batch of the oracle's size, whose pixels the
+    oracle checks (test_nerf_end_to_end_bf16)."""
     from nerf_amd.model import MipNeRF
     from nerf_amd.train import synthetic_rays
     from nerf_amd.utils import namedtuple_map
     torch.manual_seed(1)
     m = MipNeRF(cfg(False)).cuda().train()
     m.randomized = False
-    rays, _ = synthetic_rays(262144, 'cuda', seed=6)
+    n = 1 << 20
+    rays, _ = synthetic_rays(n, 'cuda', seed=6)
     with torch.no_grad():
         rgb, dist, acc = m(rays)
-        parts = [m(namedtuple_map(lambda t: t[i:i + 8192], rays)) for i in range(0, 262144, 65536)]
-    for i, (r, d, a) in enumerate(parts):
-        s = slice(i * 65536, i * 65536 + 8192)
-        assert torch.equal(r, rgb[:, s]) and torch.equal(d, dist[:, s]) and torch.equal(a, acc[:, s])
+        starts = list(range(0, n, 131072)) + [n - 8192, n - 1000]
+        parts = [m(namedtuple_map(lambda t: t[i:i + 8192], rays)) for i in starts]
+    for i, (r, d, a) in zip(starts, parts):
+        s = slice(i, min(i + 8192, n))
+        assert torch.equal(r, rgb[:, s]) and torch.equal(d, dist[:, s]) and torch.equal(a, acc[:, s]), i
+    assert rgb.shape == (2, n, 3) and bool(torch.isfinite(rgb).all())
     assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-6
     assert float(rgb.min()) >= -0.001 * 1.0001 and float(rgb.max()) <= 1.001 * 1.0001
     assert float(dist.min()) >= 2.0 - 1e-5 and float(dist.max()) <= 6.0 + 1e-5
