@@ -235,7 +235,8 @@ def test_c4_sar_step_at_reference_sizes():
     (1) Against the oracle at 96 rays (what it finishes in seconds), same network sizes, 40 m wavelength (a
         well-conditioned fp32 phase): pulses, distance, acc, loss within the 2e-2 gate of the bf16 MLP.
     (2) At the full 2048 rays the exact-fp32 path (1e-4 parity with the oracle) stands in for it: the bf16 chain
-        must give the same pulses, distances, accs and loss to 2e-2 and gradients of the same direction and size.
+        must give the same pulses, distances, accs and loss to 2e-2 and gradients of the same direction (cosine > 0.995
+        over all 28 tensors) and size (5 %).
     (3) At the radar's 3.1 cm wavelength: range-compressed profiles normalised to unit spread per level, acc in
         [0, 1], distances inside [near, far], all 28 gradients finite and non-zero."""
     from oracle import nerf_oracle as O
@@ -273,7 +274,7 @@ def test_c4_sar_step_at_reference_sizes():
     gh = torch.cat([h[4][k].reshape(-1) for k in sorted(f[4])])
     cos = float((gf * gh).sum() / (gf.norm() * gh.norm()))
     print('c4 full size: bf16 vs fp32 gradient cosine %.4f, norm ratio %.4f' % (cos, float(gh.norm() / gf.norm())))
-    assert cos > 0.9 and abs(float(gh.norm() / gf.norm()) - 1) < 0.2
+    assert cos > 0.995 and abs(float(gh.norm() / gf.norm()) - 1) < 0.05        # measured 0.9998 / 0.990
 
     # (3) the radar's wavelength
     cfg = _sar_cfg('bf16', 0.031228381041666666, R)
