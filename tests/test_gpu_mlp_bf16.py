@@ -287,13 +287,14 @@ def block_scaled_e2m3(x):
 
 
 @pytest.mark.parametrize('tag,kw,S,n', [CASES[0], CASES[1], CASES[3]])
-def test_e4m3_weight_gradient_operands(tag, kw, S, n):
+def test_mx_weight_gradient_operand_copies(tag, kw, S, n):
     """The 8/6-bit form of the saved weight-gradient operands (NERF_TFRAG_MX): (1) the activation copies are the
     e4m3 rounding of the bf16 copies, the gradient copies their block-scaled e2m3 rounding, bit for bit; (2) the
     matrix-core kernel on these operands returns dY^T X of exactly those values (fp32 summation error).
     (How far the gradients move from the bf16-operand ones is measured where the upstream gradients are those of
-    a render, test_nerf_end_to_end_bf16[c3_1k]; here they are white noise over six decades, a few hundred
-    samples of which carry the whole sum, and the figure is printed only.)"""
+    a render, test_nerf_end_to_end_bf16, and asserted with white noise in test_mlp_gradients_vs_oracle[*-mx]; here
+    the gradients are white noise over six decades, a few hundred samples of which carry the whole sum, and only the
+    median is gated.  The second run spells the format 'e4m3', the older name that `wgrad_operands` still accepts.)"""
     from nerf_amd import mlp_bf16
     from nerf_amd.model import MipNeRF
     rays = make_rays(n, 3)
